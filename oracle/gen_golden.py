@@ -1,0 +1,242 @@
+"""Generate golden vectors by running the REAL reference (imported from /root/reference).
+
+Runs only in the build container (``/root/reference`` does not exist on the GPU box); the
+``.npz`` files it writes under ``tests/golden/`` are data: explicit fp16 input streams plus the
+reference's own eviction ids, attention outputs, cache lengths and printed budget lines.
+
+    python -m oracle.gen_golden            # rewrites tests/golden/*.npz
+
+How the reference is driven:
+  * ``easykv.easykv.generate`` is called unmodified with a duck-typed model (oracle/fake_model.py);
+  * inside that model every layer's attention is computed by the reference's OWN patched forward
+    (``llama_forward`` / ``mistral_forward`` / the ``_stream`` variants) on a stub attention module
+    whose projections slice a packed hidden state and whose RoPE table is the identity for the
+    non-stream path (keys arrive already rotated) and a real table for the stream path;
+  * eviction ids are captured by wrapping ``truncate_kv_cache_silo/_liso/truncate_kv_cache``;
+  * ``keep_attention=True`` needs ``Tensor.to('cuda')`` mapped to CPU (easykv/easykv.py:182).
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import easykv_oracle as O            # noqa: E402
+from oracle.fake_model import FakeAttnModel, make_streams   # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    import easykv.easykv as E
+    import easykv.llama_patch as LP
+    import easykv.mistral_patch as MP
+    return E, LP, MP
+
+
+class _StubCache:
+    def __init__(self, k, v):
+        self.k, self.v = k, v
+
+    def get_usable_length(self, new_len, layer_idx):
+        return 0 if self.k is None else self.k.shape[2]
+
+    def update(self, k, v, layer_idx, cache_kwargs=None):
+        if self.k is not None:
+            k, v = torch.cat((self.k, k), dim=2), torch.cat((self.v, v), dim=2)
+        self.k, self.v = k, v
+        return k, v
+
+
+def reference_core(LP, MP):
+    """Attention of one layer computed by the reference's patched forward."""
+
+    def core(model, q, k_all, v_all, mask, layer):
+        hq, h, d = q.shape[1], k_all.shape[1], q.shape[3]
+        n, t = q.shape[2], k_all.shape[2]
+        llama = "llama" in model.config.architectures[0].lower()
+        mod = LP if llama else MP
+        fwd = getattr(mod, ("llama" if llama else "mistral") + ("_forward_stream" if model.streaming else "_forward"))
+        if model.streaming:
+            cos, sin = model.cos, model.sin
+        else:
+            cos, sin = torch.ones(4096, d, dtype=q.dtype), torch.zeros(4096, d, dtype=q.dtype)
+        stub = SimpleNamespace(
+            config=SimpleNamespace(pretraining_tp=1), layer_idx=layer, num_heads=hq, num_key_value_heads=h,
+            head_dim=d, hidden_size=hq * d, num_key_value_groups=hq // h, attention_dropout=0.0, training=False,
+            q_proj=lambda x: x[..., :hq * d], k_proj=lambda x: x[..., hq * d:(hq + h) * d],
+            v_proj=lambda x: x[..., (hq + h) * d:], o_proj=lambda x: x,
+            rotary_emb=lambda x, seq_len: (cos[:seq_len], sin[:seq_len]))
+        kn, vn = k_all[:, :, t - n:], v_all[:, :, t - n:]
+        hidden = torch.cat((q[0].transpose(0, 1).reshape(n, hq * d), kn[0].transpose(0, 1).reshape(n, h * d),
+                            vn[0].transpose(0, 1).reshape(n, h * d)), dim=-1).unsqueeze(0)
+        cache = _StubCache(k_all[:, :, :t - n] if t > n else None, v_all[:, :, :t - n] if t > n else None)
+        # true positions only matter for the table length here (identity table on the non-stream path)
+        pos = torch.arange(t - n, t).view(1, -1)
+        out, w, _ = fwd(stub, hidden, attention_mask=mask, position_ids=pos, past_key_value=cache,
+                        output_attentions=True, use_cache=True, attn_device="cpu")
+        return out.view(1, n, hq, d).transpose(1, 2), w
+
+    return core
+
+
+@contextlib.contextmanager
+def cuda_to_cpu_shim():
+    orig = torch.Tensor.to
+
+    def to(self, *a, **kw):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        return orig(self, *a, **kw)
+
+    torch.Tensor.to = to
+    try:
+        yield
+    finally:
+        torch.Tensor.to = orig
+
+
+def run_reference(E, core, case, streams):
+    qs, ks, vs = streams
+    model = FakeAttnModel(qs, ks, vs, arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False), core=core)
+    log = []
+    orig = (E.truncate_kv_cache_silo, E.truncate_kv_cache_liso, E.truncate_kv_cache)
+
+    def silo(kv, ids):
+        log.append(("per_head", torch.tensor(ids).unsqueeze(-1)))
+        return orig[0](kv, ids)
+
+    def liso(kv, ids):
+        log.append(("per_head", ids.clone()))
+        return orig[1](kv, ids)
+
+    def plain(kv, start, end):
+        log.append(("range", (int(start), int(end))))
+        return orig[2](kv, start, end)
+
+    E.truncate_kv_cache_silo, E.truncate_kv_cache_liso, E.truncate_kv_cache = silo, liso, plain
+    cfg = dict(case["config"], eos_token_ids=[-1])
+    ids = torch.arange(case["length"]).view(1, -1) % 16
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf), cuda_to_cpu_shim():
+            res = E.generate(self=model, input_ids=ids, generation_config=cfg, kv_mode=case["mode"], stride=case["stride"])
+    finally:
+        E.truncate_kv_cache_silo, E.truncate_kv_cache_liso, E.truncate_kv_cache = orig
+    return model, log, res, buf.getvalue().strip()
+
+
+def run_oracle(case, streams):
+    qs, ks, vs = streams
+    model = FakeAttnModel(qs, ks, vs, arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False))
+    cfg = dict(case["config"], eos_token_ids=[-1])
+    ids = torch.arange(case["length"]).view(1, -1) % 16
+    tr = O.generate(model, ids, cfg, kv_mode=case["mode"], stride=case["stride"])
+    return model, tr
+
+
+def cases():
+    out = []
+
+    def add(name, **kw):
+        kw.setdefault("dims", dict(L=2, Hq=4, H=4, D=32))
+        kw.setdefault("stride", 1)
+        kw.setdefault("seed", 1234)
+        kw["name"] = name
+        out.append(kw)
+
+    for pol in ("roco", "h2o_head", "tova", "recency"):
+        add(f"dec_{pol}", mode="decoding", length=16, config=dict(budget=24, kv_policy=pol, max_new_tokens=60))
+    add("dec_full", mode="decoding", length=16, config=dict(budget=24, kv_policy="full", max_new_tokens=30))
+    for pol in ("roco", "h2o_head", "tova", "recency"):
+        add(f"enc_{pol}_s4", mode="encoding", stride=4, length=100, config=dict(budget=0.5, kv_policy=pol, max_new_tokens=4))
+    add("enc_roco_s7", mode="encoding", stride=7, length=101, config=dict(budget=0.5, kv_policy="roco", max_new_tokens=3))
+    add("enc_roco_s4_keep", mode="encoding", stride=4, length=100,
+        config=dict(budget=0.5, kv_policy="roco", keep_attention=True, max_new_tokens=2))
+    add("enc_h2o_s7_keep_int", mode="encoding", stride=7, length=101,
+        config=dict(budget=40, kv_policy="h2o_head", keep_attention=True, max_new_tokens=2))
+    add("enc_roco_s16", mode="encoding", stride=16, length=112, config=dict(budget=0.5, kv_policy="roco", max_new_tokens=2))
+    for pol in ("roco", "tova", "recency"):
+        add(f"auto_{pol}_s4", mode="auto", stride=4, length=96, config=dict(budget=40, kv_policy=pol, max_new_tokens=24))
+    add("auto_to_decoding", mode="auto", stride=4, length=20, config=dict(budget=44, kv_policy="roco", max_new_tokens=40))
+    add("ppl_roco_s4", mode="ppl", stride=4, length=100, config=dict(budget=0.5, kv_policy="roco"))
+    add("ppl_full", mode="ppl", stride=4, length=40, config=dict(budget=1.0, kv_policy="roco"))
+    add("dec_roco_gqa", mode="decoding", length=16, dims=dict(L=2, Hq=8, H=2, D=32), arch="MistralForCausalLM",
+        config=dict(budget=24, kv_policy="roco", max_new_tokens=60))
+    add("enc_roco_gqa_s4", mode="encoding", stride=4, length=100, dims=dict(L=2, Hq=8, H=2, D=32), arch="MistralForCausalLM",
+        config=dict(budget=0.3, kv_policy="roco", max_new_tokens=3))
+    add("enc_h2o_gqa_s8_keep", mode="encoding", stride=8, length=96, dims=dict(L=2, Hq=8, H=2, D=32), arch="MistralForCausalLM",
+        config=dict(budget=0.3, kv_policy="h2o_head", keep_attention=True, max_new_tokens=2))
+    add("enc_roco_stream_s4", mode="encoding", stride=4, length=100, streaming=True,
+        config=dict(budget=0.5, kv_policy="roco", streaming=True, max_new_tokens=3))
+    add("dec_roco_stream", mode="decoding", length=16, streaming=True,
+        config=dict(budget=24, kv_policy="roco", streaming=True, max_new_tokens=50))
+    add("ppl_roco_stream_s4", mode="ppl", stride=4, length=100, streaming=True,
+        config=dict(budget=0.4, kv_policy="roco", streaming=True))
+    add("dec_roco_d128", mode="decoding", length=8, dims=dict(L=2, Hq=4, H=4, D=128),
+        config=dict(budget=64, kv_policy="roco", max_new_tokens=120))
+    add("enc_roco_d128_s8", mode="encoding", stride=8, length=160, dims=dict(L=1, Hq=4, H=4, D=128),
+        config=dict(budget=0.5, kv_policy="roco", max_new_tokens=2))
+    return out
+
+
+def pack_log(log):
+    per_head = [x for kind, x in log if kind == "per_head"]
+    ranges = [x for kind, x in log if kind == "range"]
+    kinds = np.array([0 if kind == "per_head" else 1 for kind, _ in log], dtype=np.int8)
+    # ragged in k (auto mode: stride ids per prefill step, then 1 per decode step): ids are stored
+    # sorted along k and concatenated on the last axis, with the per-step k in ``evict_k``
+    ks = np.array([x.shape[-1] for x in per_head], dtype=np.int32)
+    ph = (torch.cat([torch.sort(x, dim=-1)[0] for x in per_head], dim=-1).numpy().astype(np.int32)
+          if per_head else np.zeros((0, 0, 0), np.int32))
+    rg = np.array(ranges, dtype=np.int32).reshape(-1, 2)
+    return kinds, ph, rg, ks
+
+
+def main():
+    E, LP, MP = _import_reference()
+    core = reference_core(LP, MP)
+    os.makedirs(OUT, exist_ok=True)
+    summary = {}
+    for case in cases():
+        d = case["dims"]
+        max_pos = case["length"] + case["config"].get("max_new_tokens", 0) + 8
+        streams = make_streams(d["L"], d["Hq"], d["H"], d["D"], max_pos, case["seed"])
+        model, log, res, printed = run_reference(E, core, case, streams)
+        kinds, ph, rg, ek = pack_log(log)
+        outs = model.outputs_log
+        out_lens = np.array([o.shape[2] for o in outs], dtype=np.int32)
+        out_cat = torch.cat(outs, dim=2).numpy().astype(np.float32)          # [L,Hq,sum n,D]
+        # cross-check: the oracle must already agree before the fixture is written
+        omodel, tr = run_oracle(case, streams)
+        okinds, oph, org, oek = pack_log([(e["kind"], e.get("ids", e.get("range"))) for e in tr.evictions])
+        same_ids = bool(np.array_equal(ph, oph) and np.array_equal(rg, org) and np.array_equal(kinds, okinds) and np.array_equal(ek, oek))
+        max_do = max((float((a - b).abs().max()) for a, b in zip(outs, omodel.outputs_log)), default=0.0)
+        meta = dict(name=case["name"], mode=case["mode"], stride=case["stride"], length=case["length"], dims=d,
+                    config=case["config"], arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False),
+                    printed=printed, result=(res if isinstance(res, float) else str(res)), n_forwards=len(outs))
+        np.savez_compressed(os.path.join(OUT, case["name"] + ".npz"), meta=json.dumps(meta),
+                            qs=streams[0].numpy(), ks=streams[1].numpy(), vs=streams[2].numpy(),
+                            evict_kinds=kinds, evict_ids=ph, evict_k=ek, evict_ranges=rg, out_lens=out_lens, outputs=out_cat)
+        summary[case["name"]] = dict(printed=printed, evict_steps=int(len(kinds)), oracle_ids_equal=same_ids, oracle_max_abs_out=max_do)
+        print(case["name"], summary[case["name"]])
+    with open(os.path.join(OUT, "SUMMARY.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    bad = [k for k, v in summary.items() if not v["oracle_ids_equal"]]
+    print("oracle mismatches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,54 @@
+"""Loading of the committed golden vectors (tests/golden/*.npz, written by oracle/gen_golden.py)."""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    g = dict(meta=meta,
+             streams=(torch.from_numpy(z["qs"]), torch.from_numpy(z["ks"]), torch.from_numpy(z["vs"])),
+             kinds=z["evict_kinds"], ids=z["evict_ids"], k=z["evict_k"], ranges=z["evict_ranges"],
+             out_lens=z["out_lens"], outputs=torch.from_numpy(z["outputs"]))
+    return g
+
+
+def split_ids(g):
+    """-> list over per-head eviction steps of int arrays [L,H,k] (sorted along k)."""
+    out, off = [], 0
+    for k in g["k"]:
+        out.append(g["ids"][..., off:off + int(k)])
+        off += int(k)
+    return out
+
+
+def split_outputs(g):
+    """-> list over forwards of tensors [L,Hq,n,D]."""
+    out, off = [], 0
+    for n in g["out_lens"]:
+        out.append(g["outputs"][:, :, off:off + int(n)])
+        off += int(n)
+    return out
+
+
+def trace_events(trace):
+    """Normalise an oracle/product Trace to (kinds, [sorted per-head ids], [ranges])."""
+    kinds, ph, rg = [], [], []
+    for e in trace.evictions:
+        if e["kind"] == "per_head":
+            kinds.append(0)
+            ph.append(np.sort(np.asarray(e["ids"]).astype(np.int32), axis=-1))
+        else:
+            kinds.append(1)
+            rg.append(tuple(int(x) for x in e["range"]))
+    return np.array(kinds, dtype=np.int8), ph, rg
