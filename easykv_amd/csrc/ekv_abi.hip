@@ -1,0 +1,319 @@
+// C ABI of the MI355X-native budgeted-KV attention path (see include/easykv_hip.h) + utility kernels.
+#include <algorithm>
+
+#include "ekv_common.h"
+#include "ekv_kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// utility kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void ekv_iota_rows_kernel(int32_t* slot, int cap, size_t n_rows) {
+  const size_t row = blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < cap; j += gridDim.x * blockDim.x) slot[row * cap + j] = j;
+  (void)n_rows;
+}
+
+// easykv/easykv.py:242-245 (mode 0), :412-416 (modes 1, 2)
+__global__ void ekv_state_init_kernel(float* s, float* q, float* c, int cap, int width, int mode, int stride,
+                                      size_t row0) {
+  const size_t row = row0 + blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < cap; j += gridDim.x * blockDim.x) {
+    float cv = 0.f;
+    if (j < width) {
+      if (mode == 0) cv = (float)(width - 1 - j);
+      else if (mode == 1) cv = (float)(width - j) - (float)stride;
+      else cv = j < width - stride ? 0.f : -(float)(j - (width - stride));
+    }
+    s[row * cap + j] = 0.f;
+    q[row * cap + j] = 0.f;
+    c[row * cap + j] = cv;
+  }
+}
+
+// one 16-byte lane per 8 halfs; rows of D halfs
+template <bool GATHER>
+__global__ void ekv_rows_copy_kernel(__half* bank_k, __half* bank_v, const int32_t* slot, __half* lin_k, __half* lin_v,
+                                     int n_kv_heads, int cap, int D, int layer_begin, int pos_begin, int n) {
+  const int h = blockIdx.y, ll = blockIdx.z;
+  const size_t head_row = ((size_t)(layer_begin + ll) * n_kv_heads + h) * cap;
+  const int lpr = D / 8;
+  const int rows_per_block = blockDim.x / lpr;
+  const int sub = threadIdx.x % lpr;
+  for (int i = blockIdx.x * rows_per_block + threadIdx.x / lpr; i < n; i += gridDim.x * rows_per_block) {
+    const int row = slot[head_row + pos_begin + i];
+    uint4* bk = reinterpret_cast<uint4*>(bank_k + (head_row + row) * D) + sub;
+    uint4* bv = reinterpret_cast<uint4*>(bank_v + (head_row + row) * D) + sub;
+    uint4* lk = reinterpret_cast<uint4*>(lin_k + (((size_t)ll * n_kv_heads + h) * n + i) * D) + sub;
+    uint4* lv = reinterpret_cast<uint4*>(lin_v + (((size_t)ll * n_kv_heads + h) * n + i) * D) + sub;
+    if (GATHER) {
+      *lk = *bk;
+      *lv = *bv;
+    } else {
+      *bk = *lk;
+      *bv = *lv;
+    }
+  }
+}
+
+// Reference-shaped physical compaction (easykv/easykv.py:56-82) in place, identity layout.  One workgroup per
+// (tensor, head, layer).  Destination d >= first victim takes source d + #victims <= source; chunks ascend and every
+// chunk is fully read before it is written, so a source row is never overwritten before it has been moved.
+__global__ void __launch_bounds__(256) ekv_compact_inplace_kernel(__half* k, __half* v, const int32_t* evict, int n_kv_heads,
+                                                                  int cap, int D, int layer_begin, int n_slots, int n_evict) {
+  extern __shared__ int32_t s_ev[];
+  const int which = blockIdx.x, h = blockIdx.y, ll = blockIdx.z;
+  __half* base = (which == 0 ? k : v) + ((size_t)(layer_begin + ll) * n_kv_heads + h) * cap * D;
+  for (int i = threadIdx.x; i < n_evict; i += 256) s_ev[i] = evict[((size_t)ll * n_kv_heads + h) * n_evict + i];
+  __syncthreads();
+  const int lpr = D / 8, sub = threadIdx.x % lpr, rg = threadIdx.x / lpr, rpb = 256 / lpr;
+  constexpr int CH = 4;  // rows per thread per chunk
+  const int first = s_ev[0], n_keep = n_slots - n_evict;
+  for (int d0 = first; d0 < n_keep; d0 += rpb * CH) {
+    uint4 buf[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int d = d0 + c * rpb + rg;
+      if (d < n_keep) {
+        int src = d;
+        for (int e = 0; e < n_evict && s_ev[e] <= src; ++e) src++;
+        buf[c] = reinterpret_cast<const uint4*>(base + (size_t)src * D)[sub];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int d = d0 + c * rpb + rg;
+      if (d < n_keep) reinterpret_cast<uint4*>(base + (size_t)d * D)[sub] = buf[c];
+    }
+    __syncthreads();
+  }
+}
+
+int check_bank(const ekv_bank* b) {
+  if (!b || !b->k || !b->v || !b->slot_of_pos) return EKV_E_ARG;
+  if (b->n_layers <= 0 || b->n_kv_heads <= 0 || b->n_q_heads % b->n_kv_heads || b->cap <= 0) return EKV_E_ARG;
+  if (b->head_dim != 32 && b->head_dim != 64 && b->head_dim != 128) return EKV_E_UNSUPPORTED;
+  return EKV_OK;
+}
+
+int check_layers(const ekv_bank* b, int begin, int count) {
+  return (begin < 0 || count <= 0 || begin + count > b->n_layers) ? EKV_E_ARG : EKV_OK;
+}
+
+}  // namespace
+
+EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
+  EkvWs w{};
+  const int T = st->n_slots;
+  w.t_pad = (int)ekv_align((size_t)T, 64);
+  // key-range splits: aim for >= 1024 workgroups, never fewer than 256 positions per split
+  const int wg_unit = st->q_len == 1 ? 128 : 64;
+  int n_split = st->n_split;
+  if (n_split <= 0) {
+    const int heads = st->layer_count * bank->n_kv_heads;
+    n_split = std::max(1, std::min((1024 + heads - 1) / heads, (T + 255) / 256));
+  }
+  int rows = (int)ekv_align((size_t)(T + n_split - 1) / n_split, wg_unit);
+  w.rows_per_split = rows;
+  w.n_split = (T + rows - 1) / rows;
+  const size_t rowsq = (size_t)st->layer_count * bank->n_q_heads * st->q_len;
+  size_t off = 0;
+  char* p = static_cast<char*>(base);
+  w.logits = reinterpret_cast<float*>(p + off);
+  off += ekv_align(rowsq * w.t_pad * 4, 256);
+  w.partials = reinterpret_cast<float*>(p + off);
+  off += ekv_align(rowsq * w.n_split * (bank->head_dim + 2) * 4, 256);
+  w.tova_row = reinterpret_cast<float*>(p + off);
+  off += ekv_align((size_t)st->layer_count * w.t_pad * 4, 256);
+  w.bytes = off;
+  return w;
+}
+
+extern "C" {
+
+int ekv_abi_version(void) { return EKV_ABI_VERSION; }
+
+const char* ekv_strerror(int code) {
+  switch (code) {
+    case EKV_OK: return "ok";
+    case EKV_E_ARG: return "invalid argument (null pointer or inconsistent sizes)";
+    case EKV_E_UNSUPPORTED: return "unsupported shape (head_dim, group size, q_len or row width)";
+    case EKV_E_WORKSPACE: return "workspace too small";
+    case EKV_E_LAUNCH: return "kernel launch failed";
+    default: return "unknown error";
+  }
+}
+
+size_t ekv_workspace_bytes(const ekv_bank* bank, const ekv_step* step) {
+  if (!bank || !step) return 0;
+  return ekv_plan_workspace(bank, step, nullptr).bytes;
+}
+
+int ekv_bank_reset(const ekv_bank* bank, void* stream) {
+  if (int e = check_bank(bank)) return e;
+  const size_t rows = (size_t)bank->n_layers * bank->n_kv_heads;
+  hipLaunchKernelGGL(ekv_iota_rows_kernel, dim3((bank->cap + 255) / 256, (unsigned)rows), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), bank->slot_of_pos, bank->cap, rows);
+  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+}
+
+int ekv_state_init(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t width, int32_t mode,
+                   int32_t stride, void* stream) {
+  if (int e = check_bank(bank)) return e;
+  if (int e = check_layers(bank, layer_begin, layer_count)) return e;
+  if (!bank->score_sum || !bank->score_sq || !bank->score_cnt || width < 0 || width > bank->cap || mode < 0 || mode > 2)
+    return EKV_E_ARG;
+  const size_t row0 = (size_t)layer_begin * bank->n_kv_heads;
+  hipLaunchKernelGGL(ekv_state_init_kernel, dim3((bank->cap + 255) / 256, layer_count * bank->n_kv_heads), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), bank->score_sum, bank->score_sq, bank->score_cnt, bank->cap, width,
+                     mode, stride, row0);
+  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+}
+
+int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, const void* k_new, const void* v_new,
+                    void* out, int32_t* evict_ids, const float* rope_cos, const float* rope_sin, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  if (int e = check_bank(bank)) return e;
+  if (!st || !q || !k_new || !v_new || !out || !workspace) return EKV_E_ARG;
+  if (int e = check_layers(bank, st->layer_begin, st->layer_count)) return e;
+  const int T = st->n_slots, n = st->q_len;
+  if (n < 1 || T < n || T > bank->cap || st->n_evict < 0 || st->n_evict >= T) return EKV_E_ARG;
+  const bool scored =
+      st->policy == EKV_POLICY_H2O_HEAD || st->policy == EKV_POLICY_ROCO || st->policy == EKV_POLICY_TOVA;
+  if (scored && (!bank->score_sum || st->score_off < 0 || st->score_off >= T)) return EKV_E_ARG;
+  if (st->policy == EKV_POLICY_ROCO && (!bank->score_sq || !bank->score_cnt)) return EKV_E_ARG;
+  if (st->policy < EKV_POLICY_NONE || st->policy > EKV_POLICY_RANGE) return EKV_E_ARG;
+  if (st->rope_on_read && (!rope_cos || !rope_sin)) return EKV_E_ARG;
+  const int W = T - (scored ? st->score_off : 0);
+  if (st->n_evict > 0) {
+    if (st->policy == EKV_POLICY_NONE) return EKV_E_ARG;
+    if (st->policy == EKV_POLICY_RANGE && (st->range_start < 0 || st->range_start + st->n_evict > T)) return EKV_E_ARG;
+    if (st->policy == EKV_POLICY_ROCO && (st->roco_k1 < st->n_evict || st->roco_k1 > W)) return EKV_E_ARG;
+    if ((st->policy == EKV_POLICY_H2O_HEAD || st->policy == EKV_POLICY_TOVA) &&
+        (st->win_lo < 0 || st->win_tail < 0 || W - st->win_tail - st->win_lo < st->n_evict))
+      return EKV_E_ARG;
+  }
+  const int rep = bank->n_q_heads / bank->n_kv_heads;
+  const EkvWs ws = ekv_plan_workspace(bank, st, workspace);
+  if (ws.bytes > workspace_bytes) return EKV_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  EkvAttnArgs aa{};
+  aa.k = static_cast<const __half*>(bank->k);
+  aa.v = static_cast<const __half*>(bank->v);
+  aa.k_w = static_cast<__half*>(bank->k);
+  aa.v_w = static_cast<__half*>(bank->v);
+  aa.slot_of_pos = bank->slot_of_pos;
+  aa.q = static_cast<const __half*>(q);
+  aa.k_new = static_cast<const __half*>(k_new);
+  aa.v_new = static_cast<const __half*>(v_new);
+  aa.logits = ws.logits;
+  aa.partials = ws.partials;
+  aa.rope_cos = st->rope_on_read ? rope_cos : nullptr;
+  aa.rope_sin = st->rope_on_read ? rope_sin : nullptr;
+  aa.n_q_heads = bank->n_q_heads;
+  aa.n_kv_heads = bank->n_kv_heads;
+  aa.cap = bank->cap;
+  aa.n_slots = T;
+  aa.q_len = n;
+  aa.n_split = ws.n_split;
+  aa.rows_per_split = ws.rows_per_split;
+  aa.t_pad = ws.t_pad;
+  aa.layer_begin = st->layer_begin;
+  aa.causal = st->causal;
+  aa.sm_div = st->sm_div;
+
+  hipError_t err;
+  if (n == 1) {
+    if (!ekv_attn_decode_supported(bank->head_dim, rep)) return EKV_E_UNSUPPORTED;
+    err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
+  } else {
+    if (!ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
+    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, s);
+  }
+  if (err != hipSuccess) return EKV_E_LAUNCH;
+
+  EkvScoreArgs sa{};
+  sa.slot_of_pos = bank->slot_of_pos;
+  sa.score_sum = bank->score_sum;
+  sa.score_sq = bank->score_sq;
+  sa.score_cnt = bank->score_cnt;
+  sa.logits = ws.logits;
+  sa.partials = ws.partials;
+  sa.tova_row = ws.tova_row;
+  sa.out = static_cast<__half*>(out);
+  sa.evict_ids = evict_ids;
+  sa.n_q_heads = bank->n_q_heads;
+  sa.n_kv_heads = bank->n_kv_heads;
+  sa.head_dim = bank->head_dim;
+  sa.cap = bank->cap;
+  sa.n_slots = T;
+  sa.q_len = n;
+  sa.n_split = ws.n_split;
+  sa.t_pad = ws.t_pad;
+  sa.layer_begin = st->layer_begin;
+  sa.score_off = st->score_off;
+  sa.policy = st->policy;
+  sa.accumulate = st->accumulate;
+  sa.n_evict = st->n_evict;
+  sa.win_lo = st->win_lo;
+  sa.win_tail = st->win_tail;
+  sa.roco_k1 = st->roco_k1;
+  sa.roco_tail = st->roco_tail;
+  sa.range_start = st->range_start;
+  sa.tova_head_mean = st->tova_head_mean;
+  sa.causal = st->causal;
+  sa.count_add = st->count_add;
+  sa.count_tail_step = st->count_tail_step;
+  if (ekv_score_lds_bytes(sa) > 160 * 1024) return EKV_E_UNSUPPORTED;
+  if (st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) {
+    if (ekv_launch_tova_headmean(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+  }
+  if (ekv_launch_score_select(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+  return EKV_OK;
+}
+
+int ekv_gather_ordered(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void* k_out,
+                       void* v_out, void* stream) {
+  if (int e = check_bank(bank)) return e;
+  if (int e = check_layers(bank, layer_begin, layer_count)) return e;
+  if (!k_out || !v_out || n_slots < 0 || n_slots > bank->cap) return EKV_E_ARG;
+  if (n_slots == 0) return EKV_OK;
+  const int rpb = 256 / (bank->head_dim / 8);
+  hipLaunchKernelGGL((ekv_rows_copy_kernel<true>), dim3(std::min(64, (n_slots + rpb - 1) / rpb), bank->n_kv_heads, layer_count),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<__half*>(bank->k),
+                     static_cast<__half*>(bank->v), bank->slot_of_pos, static_cast<__half*>(k_out),
+                     static_cast<__half*>(v_out), bank->n_kv_heads, bank->cap, bank->head_dim, layer_begin, 0, n_slots);
+  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+}
+
+int ekv_scatter_rows(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t pos_begin, int32_t n,
+                     const void* k_in, const void* v_in, void* stream) {
+  if (int e = check_bank(bank)) return e;
+  if (int e = check_layers(bank, layer_begin, layer_count)) return e;
+  if (!k_in || !v_in || pos_begin < 0 || n < 0 || pos_begin + n > bank->cap) return EKV_E_ARG;
+  if (n == 0) return EKV_OK;
+  const int rpb = 256 / (bank->head_dim / 8);
+  hipLaunchKernelGGL((ekv_rows_copy_kernel<false>), dim3(std::min(64, (n + rpb - 1) / rpb), bank->n_kv_heads, layer_count),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<__half*>(bank->k),
+                     static_cast<__half*>(bank->v), bank->slot_of_pos,
+                     const_cast<__half*>(static_cast<const __half*>(k_in)),
+                     const_cast<__half*>(static_cast<const __half*>(v_in)), bank->n_kv_heads, bank->cap, bank->head_dim,
+                     layer_begin, pos_begin, n);
+  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+}
+
+int ekv_compact_inplace(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, int32_t n_evict,
+                        const int32_t* evict_ids, void* stream) {
+  if (int e = check_bank(bank)) return e;
+  if (int e = check_layers(bank, layer_begin, layer_count)) return e;
+  if (!evict_ids || n_evict <= 0 || n_evict >= n_slots || n_slots > bank->cap) return EKV_E_ARG;
+  hipLaunchKernelGGL(ekv_compact_inplace_kernel, dim3(2, bank->n_kv_heads, layer_count), dim3(256), (size_t)n_evict * 4,
+                     static_cast<hipStream_t>(stream), static_cast<__half*>(bank->k), static_cast<__half*>(bank->v),
+                     evict_ids, bank->n_kv_heads, bank->cap, bank->head_dim, layer_begin, n_slots, n_evict);
+  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+}
+
+}  // extern "C"

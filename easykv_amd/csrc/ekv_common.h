@@ -1,0 +1,71 @@
+// Shared device helpers for the easykv_amd HIP kernels (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define EKV_WAVE 64
+#define EKV_LOG2E 1.4426950408889634f
+#define EKV_NEG_INF (-__builtin_inff())
+
+typedef _Float16 ekv_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 ekv_h8 __attribute__((ext_vector_type(8)));
+
+template <int CTRL>
+__device__ __forceinline__ float ekv_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
+// All-reduce (sum) over aligned groups of LPR consecutive lanes, LPR in {4,8,16}; every lane gets the total.
+// quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror: one fused v_add_f32_dpp each.
+template <int LPR>
+__device__ __forceinline__ float ekv_group_sum(float x) {
+  x += ekv_dpp<0xB1>(x);
+  x += ekv_dpp<0x4E>(x);
+  if (LPR >= 8) x += ekv_dpp<0x141>(x);
+  if (LPR >= 16) x += ekv_dpp<0x140>(x);
+  return x;
+}
+
+__device__ __forceinline__ float ekv_dot8(const uint4& a, const uint4& b, float acc) {
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(ekv_h2, a.x), __builtin_bit_cast(ekv_h2, b.x), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(ekv_h2, a.y), __builtin_bit_cast(ekv_h2, b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(ekv_h2, a.z), __builtin_bit_cast(ekv_h2, b.z), acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(ekv_h2, a.w), __builtin_bit_cast(ekv_h2, b.w), acc, false);
+  return acc;
+}
+
+__device__ __forceinline__ void ekv_axpy8(float p, const uint4& v, float (&o)[8]) {
+  const ekv_h8 h = __builtin_bit_cast(ekv_h8, v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaf(p, (float)h[i], o[i]);
+}
+
+__device__ __forceinline__ float ekv_wave_max(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+  return x;
+}
+__device__ __forceinline__ float ekv_wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+__device__ __forceinline__ unsigned long long ekv_wave_min_u64(unsigned long long x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long y = __shfl_xor(x, off, 64);
+    x = y < x ? y : x;
+  }
+  return x;
+}
+
+// Order-preserving float -> uint32 key (ascending); every NaN maps to the largest key, which is how
+// torch.topk(largest=False) ranks NaN.
+__device__ __forceinline__ uint32_t ekv_fkey(float x) {
+  if (x != x) return 0xFFFFFFFFu;
+  const uint32_t b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+static inline __host__ __device__ size_t ekv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }

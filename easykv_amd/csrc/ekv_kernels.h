@@ -1,0 +1,59 @@
+// Internal launch interface between the C ABI (ekv_abi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/easykv_hip.h"
+
+// Workspace carve-up for one ekv_step_attend call.
+struct EkvWs {
+  float* logits;    // [layer_count][Hq][q_len][t_pad]   raw q.k/sm_div of every live position
+  float* partials;  // [layer_count][Hq][q_len][n_split][D+2]   (m, l, o[D]) per key-range split
+  float* tova_row;  // [layer_count][t_pad]   head-averaged last-query row (tova_head_mean)
+  int32_t t_pad, n_split, rows_per_split;
+  size_t bytes;
+};
+
+struct EkvAttnArgs {
+  const __half* k;
+  const __half* v;
+  __half* k_w;  // same buffers, writable (append of the new rows)
+  __half* v_w;
+  const int32_t* slot_of_pos;
+  const __half* q;
+  const __half* k_new;
+  const __half* v_new;
+  float* logits;
+  float* partials;
+  const float* rope_cos;
+  const float* rope_sin;
+  int32_t n_q_heads, n_kv_heads, cap, n_slots, q_len, n_split, rows_per_split, t_pad, layer_begin, causal;
+  float sm_div;
+};
+
+struct EkvScoreArgs {
+  int32_t* slot_of_pos;
+  float* score_sum;
+  float* score_sq;
+  float* score_cnt;
+  const float* logits;
+  const float* partials;
+  float* tova_row;
+  __half* out;
+  int32_t* evict_ids;
+  int32_t n_q_heads, n_kv_heads, head_dim, cap, n_slots, q_len, n_split, t_pad, layer_begin;
+  int32_t score_off, policy, accumulate, n_evict, win_lo, win_tail, roco_k1, roco_tail, range_start, tova_head_mean,
+      causal;
+  float count_add, count_tail_step;
+};
+
+EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* step, void* base);
+
+hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_count, hipStream_t s);
+hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, hipStream_t s);
+hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
+hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);
+bool ekv_attn_decode_supported(int head_dim, int rep);
+bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len);
+size_t ekv_score_lds_bytes(const EkvScoreArgs& a);

@@ -1,0 +1,168 @@
+"""Device-resident budgeted KV bank driven through the C ABI (include/easykv_hip.h).
+
+PyTorch is used for device memory and streams only; every operation on the bank is a HIP kernel
+of ``libeasykv_hip.so``.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import Bank, Step, check
+
+DECODE_RECENT_RATIO = 0.3   # easykv/easykv.py:308, :709 (hard-wired in the reference)
+ROCO_TAIL = 10              # easykv/easykv.py:321, :472, :721
+
+
+@dataclass
+class StepPlan:
+    """What the driver decides for one model forward; identical for every layer (mirrors the
+    branches of easykv/easykv.py:287-362 for ``phase='decode'`` and :443-499 for ``'prefill'``)."""
+    policy: str = "roco"
+    phase: str = "decode"
+    accumulate: bool = True
+    evict: bool = False
+    score_off: int = 0          # P: first position covered by the score rows
+    budget: int = 0             # decode: budget ; prefill: budget' (= budget + stride)
+    recent: int = 0             # prefill: int(budget' * recent_ratio)
+    sink: int = 0               # prefill: temp_length
+    stride: int = 1
+    tova_head_mean: bool = False
+    range_start: int = -1       # recency / random
+    streaming: bool = False
+    n_split: int = 0
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class KVBank:
+    """K/V rows + slot map + score rows of ``n_layers`` layers on one GPU."""
+
+    def __init__(self, n_layers, n_q_heads, n_kv_heads, head_dim, cap, device="cuda", scored=True):
+        self.lib = _lib.load()
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.EkvError("KVBank needs a GPU device; the product path has no CPU fallback")
+        self.device = dev
+        self.n_layers, self.n_q_heads, self.n_kv_heads, self.head_dim, self.cap = n_layers, n_q_heads, n_kv_heads, head_dim, cap
+        self.k = torch.empty(n_layers, n_kv_heads, cap, head_dim, dtype=torch.float16, device=dev)
+        self.v = torch.empty_like(self.k)
+        self.slot_of_pos = torch.empty(n_layers, n_kv_heads, cap, dtype=torch.int32, device=dev)
+        self.score_sum = torch.zeros(n_layers, n_kv_heads, cap, dtype=torch.float32, device=dev) if scored else None
+        self.score_sq = torch.zeros_like(self.score_sum) if scored else None
+        self.score_cnt = torch.zeros_like(self.score_sum) if scored else None
+        self.n_slots = [0] * n_layers
+        self._ws = None
+        self._bank = Bank(self.k.data_ptr(), self.v.data_ptr(), self.slot_of_pos.data_ptr(),
+                          self.score_sum.data_ptr() if scored else None, self.score_sq.data_ptr() if scored else None,
+                          self.score_cnt.data_ptr() if scored else None, n_layers, n_q_heads, n_kv_heads, head_dim, cap)
+        self.rope_cos = self.rope_sin = None
+        self.reset()
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def reset(self):
+        check(self.lib.ekv_bank_reset(C.byref(self._bank), self._stream()), "ekv_bank_reset")
+        self.n_slots = [0] * self.n_layers
+
+    def state_init(self, width, mode, stride=1, layer_begin=0, layer_count=None):
+        """mode 0 decoding (easykv/easykv.py:242-245); 1 prefill+keep_attention; 2 prefill (:412-416)."""
+        lc = self.n_layers - layer_begin if layer_count is None else layer_count
+        check(self.lib.ekv_state_init(C.byref(self._bank), layer_begin, lc, width, mode, stride, self._stream()), "ekv_state_init")
+
+    def set_rope(self, cos, sin):
+        """fp32 tables ``[>= cap, head_dim]`` for the streaming (rope-on-read) variant."""
+        self.rope_cos = cos.to(self.device, torch.float32).contiguous()
+        self.rope_sin = sin.to(self.device, torch.float32).contiguous()
+
+    # -- data movement at the boundary -------------------------------------------------------------
+    def load_rows(self, k, v, pos_begin=None, layer_begin=0):
+        """Append ordered rows ``[layers, H, n, D]`` at positions [pos_begin, pos_begin+n)."""
+        lc, n = k.shape[0], k.shape[2]
+        pos = self.n_slots[layer_begin] if pos_begin is None else pos_begin
+        k = k.to(self.device, torch.float16).contiguous()
+        v = v.to(self.device, torch.float16).contiguous()
+        check(self.lib.ekv_scatter_rows(C.byref(self._bank), layer_begin, lc, pos, n, _ptr(k), _ptr(v), self._stream()), "ekv_scatter_rows")
+        for l in range(layer_begin, layer_begin + lc):
+            self.n_slots[l] = pos + n
+
+    def ordered_kv(self, layer_begin=0, layer_count=None):
+        """The ordered ``[layers, H, T, D]`` view the HF legacy tuple needs (birth order)."""
+        lc = self.n_layers - layer_begin if layer_count is None else layer_count
+        t = self.n_slots[layer_begin]
+        k = torch.empty(lc, self.n_kv_heads, t, self.head_dim, dtype=torch.float16, device=self.device)
+        v = torch.empty_like(k)
+        check(self.lib.ekv_gather_ordered(C.byref(self._bank), layer_begin, lc, t, _ptr(k), _ptr(v), self._stream()), "ekv_gather_ordered")
+        return k, v
+
+    def compact_inplace(self, evict_ids, layer_begin=0):
+        """Reference-shaped physical compaction for a bank kept in identity layout."""
+        lc, _, kk = evict_ids.shape
+        t = self.n_slots[layer_begin]
+        ids = evict_ids.to(self.device, torch.int32).contiguous()
+        check(self.lib.ekv_compact_inplace(C.byref(self._bank), layer_begin, lc, t, kk, _ptr(ids), self._stream()), "ekv_compact_inplace")
+        for l in range(layer_begin, layer_begin + lc):
+            self.n_slots[l] = t - kk
+
+    # -- the fused step -----------------------------------------------------------------------------
+    def make_step(self, plan: StepPlan, q_len, layer_begin, layer_count) -> Step:
+        t = self.n_slots[layer_begin] + q_len
+        st = Step()
+        st.layer_begin, st.layer_count, st.q_len, st.n_slots = layer_begin, layer_count, q_len, t
+        st.score_off = plan.score_off
+        st.policy = _lib.POLICY_CODES.get(plan.policy, _lib.POLICY_NONE)   # unknown string = no-op, as in the reference
+        st.accumulate = int(plan.accumulate)
+        st.causal = 1
+        st.rope_on_read = int(plan.streaming)
+        st.n_split = plan.n_split
+        st.sm_div = math.sqrt(self.head_dim)
+        st.tova_head_mean = int(plan.tova_head_mean)
+        st.roco_tail = ROCO_TAIL
+        st.range_start = -1
+        if plan.evict and st.policy != _lib.POLICY_NONE:
+            if plan.phase == "decode":
+                rw = int(plan.budget * DECODE_RECENT_RATIO)
+                st.n_evict = 1
+                st.win_lo, st.win_tail = (0, rw) if plan.policy == "h2o_head" else (0, 0)
+                st.roco_k1 = plan.budget - rw
+                st.count_add, st.count_tail_step = 1.0, 0.0
+            else:
+                st.n_evict = plan.stride
+                st.win_lo, st.win_tail = plan.sink, plan.recent
+                st.roco_k1 = max(plan.budget - plan.recent - plan.sink, plan.stride)
+                st.count_add, st.count_tail_step = float(plan.stride), -1.0
+            if st.policy == _lib.POLICY_RANGE:
+                st.range_start = plan.range_start
+        return st
+
+    def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None):
+        """q ``[layers, Hq, n, D]``, k_new/v_new ``[layers, H, n, D]`` (fp16, device).
+        Returns (out ``[layers, Hq, n, D]`` fp16, evict_ids ``[layers, H, k]`` int32 or None)."""
+        lc, _, n, _ = q.shape
+        st = self.make_step(plan, n, layer_begin, lc)
+        if out is None:
+            out = torch.empty(lc, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
+        if st.n_evict > 0 and evict_ids is None:
+            evict_ids = torch.empty(lc, self.n_kv_heads, st.n_evict, dtype=torch.int32, device=self.device)
+        need = self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st))
+        ws = self._workspace(need)
+        check(self.lib.ekv_step_attend(C.byref(self._bank), C.byref(st), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(out),
+                                       _ptr(evict_ids) if st.n_evict > 0 else None, _ptr(self.rope_cos), _ptr(self.rope_sin),
+                                       _ptr(ws), ws.numel(), self._stream()), "ekv_step_attend")
+        for l in range(layer_begin, layer_begin + lc):
+            self.n_slots[l] = st.n_slots - st.n_evict
+        return out, (evict_ids if st.n_evict > 0 else None)

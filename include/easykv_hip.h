@@ -1,0 +1,146 @@
+/*
+ * easykv_hip.h — C ABI of the MI355X-native budgeted-KV-cache attention path.
+ *
+ * Drop-in boundary for the ONE hot path of DRSY/EasyKV (reference paths relative to
+ * /root/reference):  per layer and per model forward the reference does, in Python,
+ *
+ *   patched attention forward      easykv/llama_patch.py:198-222, :310-327   (mistral_patch.py:144-169, :225-241)
+ *   GQA fold of the probabilities  easykv/easykv.py:188-196
+ *   score accumulation             easykv/easykv.py:287-300, :443-457, :693-707
+ *   victim selection               easykv/easykv.py:310-347, :462-493, :711-742
+ *   K/V compaction                 easykv/easykv.py:56-82, :105-112
+ *   score-state compaction         easykv/easykv.py:315-333, :465-490
+ *
+ * The reference has no FFI of its own (it is 100 % Python); the entry points below are what a
+ * ctypes binding for this path binds (see INTEGRATION.md for the reference-side stub).  Plain
+ * pointers and sizes only, no torch types.  Every launch is asynchronous on the `stream`
+ * argument (a hipStream_t passed as void*), re-entrant per stream, and keeps no global state.
+ * Return value: 0 on success, a negative EKV_E_* code otherwise (ekv_strerror() describes it).
+ *
+ * Memory model ("bank" = the layers resident on this GPU, all device memory, caller-owned):
+ *
+ *   k, v          fp16  [n_layers][n_kv_heads][cap][head_dim]   physical rows ("slots")
+ *   slot_of_pos   int32 [n_layers][n_kv_heads][cap]             permutation: logical position -> row.
+ *                       positions [0, n_slots) are live, in the reference's birth order;
+ *                       positions [n_slots, cap) hold the free rows.
+ *   score_sum     fp32  [n_layers][n_kv_heads][cap]             S  (sum p),      index j <-> position score_off + j
+ *   score_sq      fp32  [n_layers][n_kv_heads][cap]             Q  (sum p^2)     (roco only)
+ *   score_cnt     fp32  [n_layers][n_kv_heads][cap]             C  (#queries)    (roco only)
+ *
+ * Eviction never moves K/V rows: the victim's row is recycled for the next token and only the
+ * 4-byte slot map is compacted (order-preserving, exactly the reference's list semantics).
+ * ekv_gather_ordered() materialises the ordered [T][D] view the HF legacy-tuple boundary needs;
+ * ekv_compact_inplace() is the reference-shaped physical compaction for banks kept in identity
+ * layout.
+ */
+#ifndef EASYKV_HIP_H
+#define EASYKV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EKV_ABI_VERSION 1
+
+/* kv_policy strings of the reference -> codes (easykv/easykv.py:288-300, :310-362) */
+enum {
+  EKV_POLICY_NONE = 0,     /* 'full' or any unknown string: attention only                    */
+  EKV_POLICY_H2O_HEAD = 1, /* 'h2o_head'                                                      */
+  EKV_POLICY_ROCO = 2,     /* 'roco'                                                          */
+  EKV_POLICY_TOVA = 3,     /* 'tova'                                                          */
+  EKV_POLICY_RANGE = 4     /* 'recency' / 'random': host-chosen contiguous range, all heads   */
+};
+
+enum {
+  EKV_OK = 0,
+  EKV_E_ARG = -1,          /* inconsistent sizes / null pointer          */
+  EKV_E_UNSUPPORTED = -2,  /* head_dim / group size / width not built    */
+  EKV_E_WORKSPACE = -3,    /* workspace too small                        */
+  EKV_E_LAUNCH = -4        /* hipLaunch failure (hipGetLastError)        */
+};
+
+typedef struct ekv_bank {
+  void *k, *v;
+  int32_t *slot_of_pos;
+  float *score_sum, *score_sq, *score_cnt;
+  int32_t n_layers, n_q_heads, n_kv_heads, head_dim, cap;
+} ekv_bank;
+
+/* One model forward over `layer_count` layers starting at `layer_begin` (all layers share the
+ * geometry, as in the reference where every layer's cache has the same length). */
+typedef struct ekv_step {
+  int32_t layer_begin, layer_count;
+  int32_t q_len;        /* 1 = decode, stride = prefill chunk                                            */
+  int32_t n_slots;      /* T: live positions INCLUDING the q_len new ones                                */
+  int32_t score_off;    /* P: first position covered by the score rows (decoding mode: prompt length)    */
+  int32_t policy;       /* EKV_POLICY_*                                                                   */
+  int32_t accumulate;   /* 1: add this forward's probabilities to the score rows                         */
+  int32_t n_evict;      /* victims per (layer, head) after the attention; 0 = none                       */
+  int32_t win_lo;       /* h2o/tova: first candidate index; roco: leading indices forced to 1e9 (sink)   */
+  int32_t win_tail;     /* h2o/tova: trailing indices excluded (recent window)                           */
+  int32_t roco_k1;      /* roco stage 1: size of the smallest-std feasible set                           */
+  int32_t roco_tail;    /* roco: trailing indices forced to 1e9 (10 in the reference)                    */
+  int32_t range_start;  /* EKV_POLICY_RANGE: evict positions [range_start, range_start + n_evict)        */
+  int32_t tova_head_mean; /* encoding/ppl 'tova': one head-averaged last-query row for all heads (:456)  */
+  int32_t causal;       /* 1: the last q_len positions are the chunk itself, causal inside it            */
+  int32_t rope_on_read; /* 1: streaming variant, rotate keys by position index at read time             */
+  int32_t n_split;      /* key-range splits per head (0 = choose)                                        */
+  int32_t reserved;
+  float count_add;      /* added to C before selection (1 decode, stride prefill); 0 = leave             */
+  float count_tail_step;/* C tail after compaction: tail[i] = i * count_tail_step (0 decode, -1 prefill) */
+  float sm_div;         /* logits are divided by this (sqrt(head_dim))                                   */
+  float reserved_f;
+} ekv_step;
+
+int ekv_abi_version(void);
+const char *ekv_strerror(int code);
+
+/* bytes of scratch ekv_step_attend needs for (bank, step) */
+size_t ekv_workspace_bytes(const ekv_bank *bank, const ekv_step *step);
+
+/* slot_of_pos <- identity for the whole bank */
+int ekv_bank_reset(const ekv_bank *bank, void *stream);
+
+/* Score-row initialisation for `layer_count` layers from `layer_begin` over width W:
+ *   S = Q = 0;  C[j] = c0 - j for j < ramp_from ... see easykv/easykv.py:242-245, :412-416.
+ * mode 0 (decoding, :245):            C[j] = (W-1) - j
+ * mode 1 (prefill, keep_attention):   C[j] = (W - j) - stride
+ * mode 2 (prefill, no keep):          C[j] = 0 for j < W-stride, else -(j-(W-stride))            */
+int ekv_state_init(const ekv_bank *bank, int32_t layer_begin, int32_t layer_count, int32_t width, int32_t mode,
+                   int32_t stride, void *stream);
+
+/* The fused step: append q_len new K/V rows, attention of the q_len queries over the n_slots live
+ * positions, GQA fold, score accumulation, victim selection, slot-map + score-row compaction.
+ *   q      fp16 [layer_count][n_q_heads][q_len][head_dim]
+ *   k_new  fp16 [layer_count][n_kv_heads][q_len][head_dim]   (already rotated unless rope_on_read)
+ *   v_new  fp16 [layer_count][n_kv_heads][q_len][head_dim]
+ *   out    fp16 [layer_count][n_q_heads][q_len][head_dim]
+ *   evict_ids int32 [layer_count][n_kv_heads][n_evict] or NULL: evicted logical positions, ascending
+ *   rope_cos/rope_sin fp32 [>= n_slots][head_dim] or NULL
+ * After the call the bank holds n_slots - n_evict live positions (the caller tracks that number). */
+int ekv_step_attend(const ekv_bank *bank, const ekv_step *step, const void *q, const void *k_new, const void *v_new,
+                    void *out, int32_t *evict_ids, const float *rope_cos, const float *rope_sin, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* Ordered view: k_out/v_out fp16 [layer_count][n_kv_heads][n_slots][head_dim] <- rows in position order */
+int ekv_gather_ordered(const ekv_bank *bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void *k_out,
+                       void *v_out, void *stream);
+
+/* Load ordered rows into the bank at positions [pos_begin, pos_begin+n) (prefix prefill / cache import):
+ *   k_in/v_in fp16 [layer_count][n_kv_heads][n][head_dim] */
+int ekv_scatter_rows(const ekv_bank *bank, int32_t layer_begin, int32_t layer_count, int32_t pos_begin, int32_t n,
+                     const void *k_in, const void *v_in, void *stream);
+
+/* Reference-shaped physical compaction (easykv/easykv.py:56-82) for a bank in identity layout:
+ * removes `n_evict` ascending positions per (layer, head) from the first n_slots rows in place,
+ * order-preserving.  evict_ids int32 [layer_count][n_kv_heads][n_evict]. */
+int ekv_compact_inplace(const ekv_bank *bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots,
+                        int32_t n_evict, const int32_t *evict_ids, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EASYKV_HIP_H */

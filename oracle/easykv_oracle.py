@@ -34,6 +34,10 @@ DECODE_RECENT_RATIO = 0.3
 ROCO_TAIL = 10
 ROCO_BIG = 1e9
 
+# Test hook: called as hook(select_fn, policy, s, q, c, args, ids) after every selection; the golden
+# generator uses it to measure how stable each decision is under relative perturbations.
+SELECT_HOOK = None
+
 
 # --------------------------------------------------------------------------
 # a1 / a3 / a5: attention core, RoPE-on-read, GQA fold
@@ -232,6 +236,13 @@ def roco_std(s, q, c, sink: int = 0):
 
 def select_decode(policy: str, s, q, c, budget: int):
     """easykv/easykv.py:310-337 (auto :711-740).  Returns ids ``[...]`` (one per row)."""
+    ids = _select_decode(policy, s, q, c, budget)
+    if SELECT_HOOK is not None:
+        SELECT_HOOK(_select_decode, policy, s, q, c, (budget,), ids.unsqueeze(-1))
+    return ids
+
+
+def _select_decode(policy: str, s, q, c, budget: int):
     rw = int(budget * DECODE_RECENT_RATIO)
     if policy == "h2o_head":
         return torch.argmin(s[..., :-rw], dim=-1)
@@ -247,6 +258,13 @@ def select_decode(policy: str, s, q, c, budget: int):
 
 def select_prefill(policy: str, s, q, c, budget_p: int, recent: int, sink: int, stride: int):
     """easykv/easykv.py:462-490 (auto :623-651, ppl :853-882).  Returns ids ``[..., stride]``."""
+    ids = _select_prefill(policy, s, q, c, budget_p, recent, sink, stride)
+    if SELECT_HOOK is not None:
+        SELECT_HOOK(_select_prefill, policy, s, q, c, (budget_p, recent, sink, stride), ids)
+    return ids
+
+
+def _select_prefill(policy: str, s, q, c, budget_p: int, recent: int, sink: int, stride: int):
     if policy in ("h2o_head", "tova"):
         return torch.topk(s[..., sink:-recent], dim=-1, k=stride, largest=False)[1] + sink
     if policy == "roco":
