@@ -15,7 +15,7 @@ POLICY_NONE, POLICY_H2O_HEAD, POLICY_ROCO, POLICY_TOVA, POLICY_RANGE = 0, 1, 2, 
 POLICY_CODES = {"full": POLICY_NONE, "h2o_head": POLICY_H2O_HEAD, "roco": POLICY_ROCO, "tova": POLICY_TOVA,
                 "recency": POLICY_RANGE, "random": POLICY_RANGE}
 
-EXPORTS = ("ekv_abi_version", "ekv_strerror", "ekv_workspace_bytes", "ekv_bank_reset", "ekv_state_init",
+EXPORTS = ("ekv_abi_version", "ekv_strerror", "ekv_workspace_bytes", "ekv_step_plan", "ekv_bank_reset", "ekv_state_init",
            "ekv_step_attend", "ekv_gather_ordered", "ekv_scatter_rows", "ekv_compact_inplace")
 
 
@@ -30,7 +30,7 @@ class Step(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "layer_begin", "layer_count", "q_len", "n_slots", "score_off", "policy", "accumulate", "n_evict",
         "win_lo", "win_tail", "roco_k1", "roco_tail", "range_start", "tova_head_mean", "causal", "rope_on_read",
-        "n_split", "reserved")] + [(n, C.c_float) for n in ("count_add", "count_tail_step", "sm_div", "reserved_f")]
+        "n_split", "phases")] + [(n, C.c_float) for n in ("count_add", "count_tail_step", "sm_div", "reserved_f")]
 
 
 class EkvError(RuntimeError):
@@ -58,6 +58,7 @@ def load():
     lib.ekv_strerror.argtypes = [C.c_int]
     lib.ekv_workspace_bytes.restype = C.c_size_t
     lib.ekv_workspace_bytes.argtypes = [C.POINTER(Bank), C.POINTER(Step)]
+    lib.ekv_step_plan.argtypes = [C.POINTER(Bank), C.POINTER(Step), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.ekv_bank_reset.argtypes = [C.POINTER(Bank), vp]
     lib.ekv_state_init.argtypes = [C.POINTER(Bank), i32, i32, i32, i32, i32, vp]
     lib.ekv_step_attend.argtypes = [C.POINTER(Bank), C.POINTER(Step), vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]

@@ -151,6 +151,17 @@ size_t ekv_workspace_bytes(const ekv_bank* bank, const ekv_step* step) {
   return ekv_plan_workspace(bank, step, nullptr).bytes;
 }
 
+int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, int32_t* fused) {
+  if (int e = check_bank(bank)) return e;
+  if (!st || !n_split || !fused) return EKV_E_ARG;
+  const EkvWs ws = ekv_plan_workspace(bank, st, nullptr);
+  *n_split = ws.n_split;
+  *fused = (st->q_len == 1 && st->phases == 0 && ws.n_split == 1 &&
+            ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, st->n_evict))
+               ? 1 : 0;
+  return EKV_OK;
+}
+
 int ekv_bank_reset(const ekv_bank* bank, void* stream) {
   if (int e = check_bank(bank)) return e;
   const size_t rows = (size_t)bank->n_layers * bank->n_kv_heads;
@@ -225,16 +236,6 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.causal = st->causal;
   aa.sm_div = st->sm_div;
 
-  hipError_t err;
-  if (n == 1) {
-    if (!ekv_attn_decode_supported(bank->head_dim, rep)) return EKV_E_UNSUPPORTED;
-    err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
-  } else {
-    if (!ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
-    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, s);
-  }
-  if (err != hipSuccess) return EKV_E_LAUNCH;
-
   EkvScoreArgs sa{};
   sa.slot_of_pos = bank->slot_of_pos;
   sa.score_sum = bank->score_sum;
@@ -267,6 +268,25 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   sa.causal = st->causal;
   sa.count_add = st->count_add;
   sa.count_tail_step = st->count_tail_step;
+
+  // whole decode step in one launch when no head has to be split
+  if (n == 1 && st->phases == 0 && ws.n_split == 1 &&
+      ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, st->n_evict)) {
+    return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+  }
+
+  hipError_t err = hipSuccess;
+  if (st->phases == 2) {
+  } else if (n == 1) {
+    if (!ekv_attn_decode_supported(bank->head_dim, rep)) return EKV_E_UNSUPPORTED;
+    err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
+  } else {
+    if (!ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
+    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, s);
+  }
+  if (err != hipSuccess) return EKV_E_LAUNCH;
+  if (st->phases == 1) return EKV_OK;
+
   if (ekv_score_lds_bytes(sa) > 160 * 1024) return EKV_E_UNSUPPORTED;
   if (st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) {
     if (ekv_launch_tova_headmean(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;

@@ -1,0 +1,5 @@
+// decode kernels for head_dim = 32, rope-on-read (streaming)
+#define EKV_D 32
+#define EKV_ROPE true
+#define EKV_ROPE_TAG rope
+#include "ekv_attn_decode.inc"

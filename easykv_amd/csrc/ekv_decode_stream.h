@@ -1,42 +1,37 @@
-// K1: single-token decode attention over the retained slots + logit export for the scorer.
-//
-// Replaces easykv/llama_patch.py:198-222 (mistral_patch.py:144-169) for q_len == 1, the K/V append of
-// HF DynamicCache.update (call site llama_patch.py:193-196) and, with rope_on_read, the streaming
-// rotation of llama_patch.py:310-327.
+// The streaming loop of the decode attention (shared by the split and the fused kernels).
 //
 // Mapping (D = 128): a K/V row is 256 B; 16 lanes x 16 B read one row fully coalesced along the
-// head-dim axis, a wave64 load instruction covers 4 rows, each lane keeps U = 8 K and 8 V loads in
-// flight.  QK^T is v_dot2c_f32_f16 + a 4-step fused v_add_f32_dpp butterfly over the 16 lanes of a
-// row; softmax is lane-local online (exp2), so there is no cross-row traffic inside the loop.  One
-// workgroup serves the REP query heads of one KV head (GQA: the K/V rows are read once).
-// HBM-bound: 2*H*T*D*2 bytes per layer-step; nothing is re-read.
+// head-dim axis, a wave64 load instruction covers 4 rows, each lane keeps kU = 8 K and 8 V loads in
+// flight.  QK^T is v_dot2c_f32_f16 + a fused v_add_f32_dpp butterfly over the lanes of a row; softmax is
+// lane-local online (exp2), so there is no cross-row traffic inside the loop.  One workgroup serves the
+// REP query heads of one KV head (GQA: the K/V rows are read once).
+#pragma once
 #include "ekv_common.h"
 #include "ekv_kernels.h"
-
-namespace {
 
 constexpr int kNW = 4;  // waves per workgroup
 constexpr int kU = 8;   // rows in flight per lane group (K and V each)
 
-template <int D, int REP, bool ROPE>
-__global__ void __launch_bounds__(256) ekv_attn_decode_kernel(const EkvAttnArgs a) {
-  constexpr int LPR = D / 8;    // lanes per row
-  constexpr int G = 64 / LPR;   // rows per wave-load
-  constexpr int RW = G * kU;    // rows per wave per iteration
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int32_t* s_slot = reinterpret_cast<int32_t*>(smem);
-  float* s_part = reinterpret_cast<float*>(smem + ekv_align((size_t)a.rows_per_split * 4, 16));
+template <int D>
+struct EkvDecodeGeom {
+  static constexpr int LPR = D / 8;   // lanes per row
+  static constexpr int G = 64 / LPR;  // rows per wave-load
+  static constexpr int RW = G * kU;   // rows per wave per iteration
+  static constexpr int NP = kNW * G;  // lane-group partials per workgroup
+  static constexpr int PS = D + 2;    // (m, l, o[D])
+};
 
-  const int split = blockIdx.x, h = blockIdx.y, ll = blockIdx.z;
-  const int gl = a.layer_begin + ll;
+// Streams positions [t0, t1) of KV head h.  s_slot holds slot_of_pos[t0..t1).  Logits (q.k / sm_div) go to
+// `logit_out` (+ row stride `logit_stride` per query head): global workspace or LDS.
+template <int D, int REP, bool ROPE>
+__device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
+                                                  int logit_stride, int t0, int t1, int ll, int h, size_t head_row,
+                                                  float (&m)[REP], float (&l)[REP], float (&o)[REP][8]) {
+  using Gm = EkvDecodeGeom<D>;
+  constexpr int LPR = Gm::LPR, RW = Gm::RW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
-  const int t0 = split * a.rows_per_split;
-  const int t1 = min(a.n_slots, t0 + a.rows_per_split);
-  const size_t head_row = ((size_t)gl * a.n_kv_heads + h) * a.cap;
   const int t_new = a.n_slots - 1;  // the appended position
-
-  for (int i = tid; i < t1 - t0; i += 256) s_slot[i] = a.slot_of_pos[head_row + t0 + i];
 
   uint4 qv[REP];
   float qf[REP][8], qr[REP][8];  // ROPE: rotated query and its rotate_half partner, fp32
@@ -64,7 +59,6 @@ __global__ void __launch_bounds__(256) ekv_attn_decode_kernel(const EkvAttnArgs 
       }
     }
   }
-  __syncthreads();
 
   const __half* k_new_row = a.k_new + ((size_t)ll * a.n_kv_heads + h) * D;
   const __half* v_new_row = a.v_new + ((size_t)ll * a.n_kv_heads + h) * D;
@@ -74,7 +68,6 @@ __global__ void __launch_bounds__(256) ekv_attn_decode_kernel(const EkvAttnArgs 
     reinterpret_cast<uint4*>(a.v_w + off)[sub] = reinterpret_cast<const uint4*>(v_new_row)[sub];
   }
 
-  float m[REP], l[REP], o[REP][8];
 #pragma unroll
   for (int r = 0; r < REP; ++r) {
     m[r] = EKV_NEG_INF;
@@ -89,8 +82,7 @@ __global__ void __launch_bounds__(256) ekv_attn_decode_kernel(const EkvAttnArgs 
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int j = j0 + u;
-      const bool valid = j < t1;
-      const int jj = valid ? j : t1 - 1;
+      const int jj = j < t1 ? j : t1 - 1;
       const int row = s_slot[jj - t0];
       // the appended position is read from k_new/v_new (pointer select, no branch in the hot loop)
       const bool is_new = jj == t_new;
@@ -132,8 +124,7 @@ __global__ void __launch_bounds__(256) ekv_attn_decode_kernel(const EkvAttnArgs 
         float mine = s[0];
 #pragma unroll
         for (int u = 1; u < kU; ++u) mine = (mu == u) ? s[u] : mine;
-        if (mu < kU && j0 + mu < t1)
-          a.logits[((size_t)ll * a.n_q_heads + h * REP + r) * a.t_pad + j0 + mu] = mine;
+        if (mu < kU && j0 + mu < t1) logit_out[(size_t)r * logit_stride + j0 + mu] = mine;
       }
       float mx = s[0];
 #pragma unroll
@@ -153,13 +144,18 @@ __global__ void __launch_bounds__(256) ekv_attn_decode_kernel(const EkvAttnArgs 
       m[r] = mn;
     }
   }
+}
 
-  // combine the kNW*G lane-group partials of this workgroup
-  constexpr int NP = kNW * G;
-  constexpr int PS = D + 2;
+// Lane-group partials -> LDS (call, then __syncthreads(), then ekv_decode_reduce).
+template <int D, int REP>
+__device__ __forceinline__ void ekv_decode_stash(float* s_part, const float (&m)[REP], const float (&l)[REP],
+                                                 const float (&o)[REP][8]) {
+  using Gm = EkvDecodeGeom<D>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % Gm::LPR, grp = lane / Gm::LPR;
 #pragma unroll
   for (int r = 0; r < REP; ++r) {
-    float* p = s_part + ((size_t)(wave * G + grp) * REP + r) * PS;
+    float* p = s_part + ((size_t)(wave * Gm::G + grp) * REP + r) * Gm::PS;
     if (sub == 0) {
       p[0] = m[r];
       p[1] = l[r];
@@ -167,69 +163,20 @@ __global__ void __launch_bounds__(256) ekv_attn_decode_kernel(const EkvAttnArgs 
 #pragma unroll
     for (int i = 0; i < 8; ++i) p[2 + sub * 8 + i] = o[r][i];
   }
-  __syncthreads();
-  for (int idx = tid; idx < REP * D; idx += 256) {
-    const int r = idx / D, d = idx % D;
-    float mm = EKV_NEG_INF;
-    for (int i = 0; i < NP; ++i) mm = fmaxf(mm, s_part[((size_t)i * REP + r) * PS]);
-    float ls = 0.f, os = 0.f;
-    for (int i = 0; i < NP; ++i) {
-      const float* p = s_part + ((size_t)i * REP + r) * PS;
-      const float w = (p[0] == EKV_NEG_INF) ? 0.f : exp2f((p[0] - mm) * EKV_LOG2E);
-      ls += p[1] * w;
-      os += p[2 + d] * w;
-    }
-    float* dst = a.partials + (((size_t)ll * a.n_q_heads + h * REP + r) * a.n_split + split) * PS;
-    if (d == 0) {
-      dst[0] = mm;
-      dst[1] = ls;
-    }
-    dst[2 + d] = os;
-  }
 }
 
+// Combined (max, sum, o[d]) of query head r over the workgroup's lane-group partials.
 template <int D, int REP>
-hipError_t launch(const EkvAttnArgs& a, int layer_count, hipStream_t s) {
-  constexpr int G = 64 / (D / 8);
-  const size_t lds = ekv_align((size_t)a.rows_per_split * 4, 16) + (size_t)kNW * G * REP * (D + 2) * 4;
-  const dim3 grid(a.n_split, a.n_kv_heads, layer_count);
-  if (a.rope_cos != nullptr) {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ekv_attn_decode_kernel<D, REP, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ekv_attn_decode_kernel<D, REP, true>), grid, dim3(256), lds, s, a);
-  } else {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ekv_attn_decode_kernel<D, REP, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ekv_attn_decode_kernel<D, REP, false>), grid, dim3(256), lds, s, a);
-  }
-  return hipGetLastError();
-}
-
-template <int D>
-hipError_t launch_rep(const EkvAttnArgs& a, int rep, int layer_count, hipStream_t s) {
-  switch (rep) {
-    case 1: return launch<D, 1>(a, layer_count, s);
-    case 2: return launch<D, 2>(a, layer_count, s);
-    case 4: return launch<D, 4>(a, layer_count, s);
-    case 8: return launch<D, 8>(a, layer_count, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-}  // namespace
-
-bool ekv_attn_decode_supported(int head_dim, int rep) {
-  return (head_dim == 32 || head_dim == 64 || head_dim == 128) && (rep == 1 || rep == 2 || rep == 4 || rep == 8);
-}
-
-hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_count, hipStream_t s) {
-  const int rep = a.n_q_heads / a.n_kv_heads;
-  switch (head_dim) {
-    case 32: return launch_rep<32>(a, rep, layer_count, s);
-    case 64: return launch_rep<64>(a, rep, layer_count, s);
-    case 128: return launch_rep<128>(a, rep, layer_count, s);
-    default: return hipErrorInvalidValue;
+__device__ __forceinline__ void ekv_decode_reduce(const float* s_part, int r, int d, float& mm, float& ls, float& os) {
+  using Gm = EkvDecodeGeom<D>;
+  mm = EKV_NEG_INF;
+  for (int i = 0; i < Gm::NP; ++i) mm = fmaxf(mm, s_part[((size_t)i * REP + r) * Gm::PS]);
+  ls = 0.f;
+  os = 0.f;
+  for (int i = 0; i < Gm::NP; ++i) {
+    const float* p = s_part + ((size_t)i * REP + r) * Gm::PS;
+    const float w = (p[0] == EKV_NEG_INF) ? 0.f : exp2f((p[0] - mm) * EKV_LOG2E);
+    ls += p[1] * w;
+    os += p[2 + d] * w;
   }
 }

@@ -55,5 +55,7 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 bool ekv_attn_decode_supported(int head_dim, int rep);
+bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict);
+hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, hipStream_t s);
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len);
 size_t ekv_score_lds_bytes(const EkvScoreArgs& a);

@@ -68,6 +68,40 @@ __device__ __forceinline__ unsigned long long blk_min_u64(Blk& b, unsigned long 
   return y;
 }
 
+// 8 values at once: one barrier for 8 reductions (scratch: 2 x kNWV x 8 floats)
+__device__ __forceinline__ void blk_max8(Blk& b, float (&x)[8]) {
+  float* r = reinterpret_cast<float*>(b.red) + (b.phase & 1) * kNWV * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float w = ekv_wave_max(x[i]);
+    if (b.lane == 0) r[b.wave * 8 + i] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float y = r[i];
+    for (int w = 1; w < kNWV; ++w) y = fmaxf(y, r[w * 8 + i]);
+    x[i] = y;
+  }
+  b.phase++;
+}
+__device__ __forceinline__ void blk_sum8(Blk& b, float (&x)[8]) {
+  float* r = reinterpret_cast<float*>(b.red) + (b.phase & 1) * kNWV * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float w = ekv_wave_sum(x[i]);
+    if (b.lane == 0) r[b.wave * 8 + i] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float y = 0.f;
+    for (int w = 0; w < kNWV; ++w) y += r[w * 8 + i];
+    x[i] = y;
+  }
+  b.phase++;
+}
+
 // #{ j < n : pred(key[j], j) }, pred evaluated by every thread on a strided sweep
 template <typename P>
 __device__ __forceinline__ int blk_count(Blk& b, const uint32_t* key, int n, P pred) {
@@ -141,13 +175,14 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
   float* sQ = sS + W;
   float* sC = sQ + W;
   uint32_t* sKey = reinterpret_cast<uint32_t*>(sC + W);
-  float* sRowM = reinterpret_cast<float*>(sKey + W);
+  uint32_t* sKey2 = sKey + W;
+  float* sRowM = reinterpret_cast<float*>(sKey2 + W);
   float* sRowL = sRowM + rows;
   Blk b;
   b.tid = threadIdx.x;
   b.lane = b.tid & 63;
   b.wave = b.tid >> 6;
-  b.red = reinterpret_cast<unsigned long long*>(smem + ekv_align((size_t)(4 * W + 2 * rows) * 4, 16));
+  b.red = reinterpret_cast<unsigned long long*>(smem + ekv_align((size_t)(5 * W + 2 * rows) * 4, 16));
   b.phase = 0;
 
   const size_t head_row = ((size_t)gl * a.n_kv_heads + h) * a.cap;
@@ -172,18 +207,30 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
 
   if (scored) {
     // ---- 1. exact softmax statistics of every query row (max, sum exp) over all T positions ----
+    // all threads sweep the columns; 8 rows share one pair of block reductions
     if (a.accumulate) {
-      for (int row = b.wave; row < rows; row += kNWV) {
-        const float* lg = a.logits + (hq0 * n + row) * a.t_pad;
-        float mx = EKV_NEG_INF;
-        for (int j = b.lane; j < T; j += 64) mx = fmaxf(mx, lg[j]);
-        mx = ekv_wave_max(mx);
-        float sm = 0.f;
-        for (int j = b.lane; j < T; j += 64) sm += expf(lg[j] - mx);
-        sm = ekv_wave_sum(sm);
-        if (b.lane == 0) {
-          sRowM[row] = mx;
-          sRowL[row] = sm;
+      for (int r0 = 0; r0 < rows; r0 += 8) {
+        const int nr = min(8, rows - r0);
+        const float* lg = a.logits + (hq0 * n + r0) * a.t_pad;
+        float mx[8], sm[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx[i] = EKV_NEG_INF, sm[i] = 0.f;
+        for (int j = b.tid; j < T; j += kNT) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < nr) mx[i] = fmaxf(mx[i], lg[(size_t)i * a.t_pad + j]);
+        }
+        blk_max8(b, mx);
+        for (int j = b.tid; j < T; j += kNT) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < nr) sm[i] += expf(lg[(size_t)i * a.t_pad + j] - mx[i]);
+        }
+        blk_sum8(b, sm);
+        if (b.tid == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < nr) sRowM[r0 + i] = mx[i], sRowL[r0 + i] = sm[i];
         }
       }
     }
@@ -236,10 +283,15 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
     return;
   }
 
-  // ---- 3. victim flags in sKey (1 = evict) ------------------------------------------------------
+  // ---- 3. selection: k == 1 yields `victim` directly; k > 1 leaves flags in sKey (1 = evict) -------------
+  int victim = -1;
   if (a.policy == EKV_POLICY_RANGE) {
-    for (int j = b.tid; j < W; j += kNT) sKey[j] = (j >= a.range_start && j < a.range_start + k) ? 1u : 0u;
-    __syncthreads();
+    if (k == 1) {
+      victim = a.range_start;
+    } else {
+      for (int j = b.tid; j < W; j += kNT) sKey[j] = (j >= a.range_start && j < a.range_start + k) ? 1u : 0u;
+      __syncthreads();
+    }
   } else if (a.policy == EKV_POLICY_ROCO) {
     for (int j = b.tid; j < W; j += kNT) {
       const float c = sC[j] + a.count_add;
@@ -248,26 +300,84 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
       float sd = sqrtf(sQ[j] / c - mean * mean);
       if (j >= W - a.roco_tail || j < a.win_lo) sd = 1e9f;
       sKey[j] = ekv_fkey(sd);
+      sKey2[j] = ekv_fkey(mean);
     }
     __syncthreads();
-    blk_mark_k_smallest(b, sKey, W, a.roco_k1);  // feasible set
-    for (int j = b.tid; j < W; j += kNT) sKey[j] = sKey[j] ? ekv_fkey(sS[j] / sC[j]) : 0xFFFFFFFFu;
-    __syncthreads();
-    blk_mark_k_smallest(b, sKey, W, k);
+    if (k == 1) {
+      // victim = argmin mean over F = {k1 smallest std}.  Walk the candidates in increasing (mean, index)
+      // order and take the first whose std rank is < k1: two block reductions per try instead of a k-select.
+      for (int attempt = 0; attempt < 8 && victim < 0; ++attempt) {
+        unsigned long long best = ~0ull;
+        for (int j = b.tid; j < W; j += kNT) {
+          const unsigned long long x = ((unsigned long long)sKey2[j] << 32) | (uint32_t)j;
+          best = x < best ? x : best;
+        }
+        best = blk_min_u64(b, best);
+        const int cand = (int)(best & 0xFFFFFFFFu);
+        const uint32_t sk = sKey[cand];
+        const int rank = blk_count(b, sKey, W, [sk, cand](uint32_t x, int j) { return x < sk || (x == sk && j < cand); });
+        if (rank < a.roco_k1) {
+          victim = cand;
+        } else {
+          if (b.tid == 0) sKey2[cand] = 0xFFFFFFFFu;  // not feasible: drop it from the walk
+          __syncthreads();
+        }
+      }
+    }
+    if (victim < 0) {
+      blk_mark_k_smallest(b, sKey, W, a.roco_k1);  // feasible set
+      for (int j = b.tid; j < W; j += kNT) sKey[j] = sKey[j] ? sKey2[j] : 0xFFFFFFFFu;
+      __syncthreads();
+      blk_mark_k_smallest(b, sKey, W, k);
+    }
   } else {  // h2o_head / tova: k smallest accumulated scores inside the candidate window
-    for (int j = b.tid; j < W; j += kNT)
-      sKey[j] = (j >= a.win_lo && j < W - a.win_tail) ? ekv_fkey(sS[j]) : 0xFFFFFFFFu;
+    if (k == 1) {
+      unsigned long long best = ~0ull;
+      for (int j = a.win_lo + b.tid; j < W - a.win_tail; j += kNT) {
+        const unsigned long long x = ((unsigned long long)ekv_fkey(sS[j]) << 32) | (uint32_t)j;
+        best = x < best ? x : best;
+      }
+      victim = (int)(blk_min_u64(b, best) & 0xFFFFFFFFu);
+    } else {
+      for (int j = b.tid; j < W; j += kNT)
+        sKey[j] = (j >= a.win_lo && j < W - a.win_tail) ? ekv_fkey(sS[j]) : 0xFFFFFFFFu;
+      __syncthreads();
+      blk_mark_k_smallest(b, sKey, W, k);
+    }
+  }
+  const bool roco = a.policy == EKV_POLICY_ROCO;
+
+  if (victim >= 0) {
+    // ---- 4a. single victim: everything behind it moves up by one, no scan needed ------------------------
+    if (scored) {
+      for (int d = b.tid; d < W; d += kNT) {
+        const int j = d + (d >= victim ? 1 : 0);
+        const bool tail = d == W - 1;
+        a.score_sum[head_row + d] = tail ? 0.f : sS[j];
+        if (roco) {
+          a.score_sq[head_row + d] = tail ? 0.f : sQ[j];
+          a.score_cnt[head_row + d] = tail ? 0.f : sC[j];
+        }
+      }
+    }
+    if (a.evict_ids != nullptr && b.tid == 0) a.evict_ids[(size_t)ll * a.n_kv_heads + h] = off + victim;
+    // slot map: positions >= victim shift; the victim's row becomes the free tail (recycled by the next append)
+    const int n_move = W - victim;          // entries victim .. W-1
+    int32_t* sSlot = reinterpret_cast<int32_t*>(sKey);
     __syncthreads();
-    blk_mark_k_smallest(b, sKey, W, k);
+    for (int i = b.tid; i < n_move; i += kNT) sSlot[i] = a.slot_of_pos[head_row + off + victim + i];
+    __syncthreads();
+    for (int i = b.tid; i < n_move; i += kNT)
+      a.slot_of_pos[head_row + off + victim + i] = (i == n_move - 1) ? sSlot[0] : sSlot[i + 1];
+    return;
   }
 
-  // ---- 4. destinations: kept j -> #kept before j ; evicted j -> -(1 + #evicted before j) ----------
+  // ---- 4b. destinations: kept j -> #kept before j ; evicted j -> -(1 + #evicted before j) ----------
   {
     const int items = (W + kNT - 1) / kNT;
     const int c0 = min(W, b.tid * items), c1 = min(W, c0 + items);
     int kept = 0;
     for (int j = c0; j < c1; ++j) kept += sKey[j] ? 0 : 1;
-    // block exclusive scan of `kept`
     int incl = kept;
     for (int o = 1; o < 64; o <<= 1) {
       const int y = __shfl_up(incl, o, 64);
@@ -292,7 +402,6 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
 
   // ---- 5. write back compacted score rows, evict ids -------------------------------------------------
   if (scored) {
-    const bool roco = a.policy == EKV_POLICY_ROCO;
     for (int j = b.tid; j < W; j += kNT) {
       const int d = (int)sKey[j];
       if (d >= 0) {
@@ -375,7 +484,7 @@ size_t ekv_score_lds_bytes(const EkvScoreArgs& a) {
   const bool scored = a.policy == EKV_POLICY_H2O_HEAD || a.policy == EKV_POLICY_ROCO || a.policy == EKV_POLICY_TOVA;
   const int W = a.n_slots - (scored ? a.score_off : 0);
   const int rows = (a.n_q_heads / a.n_kv_heads) * a.q_len;
-  return ekv_align((size_t)(4 * W + 2 * rows) * 4, 16) + 2 * kNWV * 8 * 2;
+  return ekv_align((size_t)(5 * W + 2 * rows) * 4, 16) + 2 * kNWV * 8 * 4;
 }
 
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s) {

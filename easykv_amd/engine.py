@@ -149,11 +149,20 @@ class KVBank:
                 st.range_start = plan.range_start
         return st
 
-    def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None):
+    def step_plan(self, plan: StepPlan, q_len, layer_begin=0, layer_count=None, phases=0):
+        """(n_split, fused) the library will use for this step."""
+        st = self.make_step(plan, q_len, layer_begin, self.n_layers - layer_begin if layer_count is None else layer_count)
+        st.phases = phases
+        ns, fu = C.c_int32(0), C.c_int32(0)
+        check(self.lib.ekv_step_plan(C.byref(self._bank), C.byref(st), C.byref(ns), C.byref(fu)), "ekv_step_plan")
+        return ns.value, bool(fu.value)
+
+    def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None, phases=0):
         """q ``[layers, Hq, n, D]``, k_new/v_new ``[layers, H, n, D]`` (fp16, device).
         Returns (out ``[layers, Hq, n, D]`` fp16, evict_ids ``[layers, H, k]`` int32 or None)."""
         lc, _, n, _ = q.shape
         st = self.make_step(plan, n, layer_begin, lc)
+        st.phases = phases
         if out is None:
             out = torch.empty(lc, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
         if st.n_evict > 0 and evict_ids is None:
@@ -163,6 +172,7 @@ class KVBank:
         check(self.lib.ekv_step_attend(C.byref(self._bank), C.byref(st), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(out),
                                        _ptr(evict_ids) if st.n_evict > 0 else None, _ptr(self.rope_cos), _ptr(self.rope_sin),
                                        _ptr(ws), ws.numel(), self._stream()), "ekv_step_attend")
-        for l in range(layer_begin, layer_begin + lc):
-            self.n_slots[l] = st.n_slots - st.n_evict
+        if phases != 1:     # phases == 1 launches the attention kernel only; the slot map is untouched
+            for l in range(layer_begin, layer_begin + lc):
+                self.n_slots[l] = st.n_slots - st.n_evict
         return out, (evict_ids if st.n_evict > 0 else None)

@@ -88,7 +88,7 @@ typedef struct ekv_step {
   int32_t causal;       /* 1: the last q_len positions are the chunk itself, causal inside it            */
   int32_t rope_on_read; /* 1: streaming variant, rotate keys by position index at read time             */
   int32_t n_split;      /* key-range splits per head (0 = choose)                                        */
-  int32_t reserved;
+  int32_t phases;       /* 0 = whole step; 1 = attention kernel only; 2 = score/select kernel only (profiling) */
   float count_add;      /* added to C before selection (1 decode, stride prefill); 0 = leave             */
   float count_tail_step;/* C tail after compaction: tail[i] = i * count_tail_step (0 decode, -1 prefill) */
   float sm_div;         /* logits are divided by this (sqrt(head_dim))                                   */
@@ -100,6 +100,10 @@ const char *ekv_strerror(int code);
 
 /* bytes of scratch ekv_step_attend needs for (bank, step) */
 size_t ekv_workspace_bytes(const ekv_bank *bank, const ekv_step *step);
+
+/* How ekv_step_attend will run (bank, step): *n_split = key-range splits per head, *fused = 1 when the whole
+ * step is ONE launch (ekv_decode_fused_kernel), 0 when it is attention kernel + score/select kernel. */
+int ekv_step_plan(const ekv_bank *bank, const ekv_step *step, int32_t *n_split, int32_t *fused);
 
 /* slot_of_pos <- identity for the whole bank */
 int ekv_bank_reset(const ekv_bank *bank, void *stream);
