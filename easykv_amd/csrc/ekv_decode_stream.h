@@ -88,8 +88,10 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
       const bool is_new = jj == t_new;
       const __half* kp = is_new ? k_new_row : a.k + (head_row + row) * D;
       const __half* vp = is_new ? v_new_row : a.v + (head_row + row) * D;
-      kr[u] = reinterpret_cast<const uint4*>(kp)[sub];
-      vr[u] = reinterpret_cast<const uint4*>(vp)[sub];
+      // K/V rows are read exactly once per step and the cache (>1 GB) never fits L2/MALL: non-temporal loads
+      // (measured on MI355X: 5.5 -> 6.1 TB/s on the pure stream)
+      kr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(kp) + sub));
+      vr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(vp) + sub));
     }
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
