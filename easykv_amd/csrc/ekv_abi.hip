@@ -107,24 +107,35 @@ int check_layers(const ekv_bank* b, int begin, int count) {
 EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   EkvWs w{};
   const int T = st->n_slots;
+  const int rep = bank->n_q_heads / bank->n_kv_heads;
+  const bool scored =
+      st->policy == EKV_POLICY_H2O_HEAD || st->policy == EKV_POLICY_ROCO || st->policy == EKV_POLICY_TOVA;
   w.t_pad = (int)ekv_align((size_t)T, 64);
+  w.qb_rows = 1;
+  w.n_qblocks = 1;
+  int qpw = 1;
+  if (st->q_len > 1) ekv_chunk_blocks(rep, st->q_len, &w.qb_rows, &w.n_qblocks, &qpw);
   // key-range splits: aim for >= 1024 workgroups, never fewer than 256 positions per split
   const int wg_unit = st->q_len == 1 ? 128 : 64;
   int n_split = st->n_split;
   if (n_split <= 0) {
-    const int heads = st->layer_count * bank->n_kv_heads;
-    n_split = std::max(1, std::min((1024 + heads - 1) / heads, (T + 255) / 256));
+    const int wgs = st->layer_count * bank->n_kv_heads * w.n_qblocks;
+    n_split = std::max(1, std::min((1024 + wgs - 1) / wgs, (T + 255) / 256));
   }
   int rows = (int)ekv_align((size_t)(T + n_split - 1) / n_split, wg_unit);
   w.rows_per_split = rows;
   w.n_split = (T + rows - 1) / rows;
+  w.n_partials = st->q_len == 1 ? w.n_split : 2 * w.n_split;
   const size_t rowsq = (size_t)st->layer_count * bank->n_q_heads * st->q_len;
   size_t off = 0;
   char* p = static_cast<char*>(base);
-  w.logits = reinterpret_cast<float*>(p + off);
-  off += ekv_align(rowsq * w.t_pad * 4, 256);
+  w.logits = nullptr;
+  if (scored && st->accumulate) {   // the scorer only needs the logits when it accumulates
+    w.logits = reinterpret_cast<float*>(p + off);
+    off += ekv_align(rowsq * w.t_pad * 4, 256);
+  }
   w.partials = reinterpret_cast<float*>(p + off);
-  off += ekv_align(rowsq * w.n_split * (bank->head_dim + 2) * 4, 256);
+  off += ekv_align(rowsq * w.n_partials * (bank->head_dim + 2) * 4, 256);
   w.tova_row = reinterpret_cast<float*>(p + off);
   off += ekv_align((size_t)st->layer_count * w.t_pad * 4, 256);
   w.bytes = off;
@@ -234,6 +245,8 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.t_pad = ws.t_pad;
   aa.layer_begin = st->layer_begin;
   aa.causal = st->causal;
+  aa.qb_rows = ws.qb_rows;
+  aa.n_qblocks = ws.n_qblocks;
   aa.sm_div = st->sm_div;
 
   EkvScoreArgs sa{};
@@ -252,7 +265,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   sa.cap = bank->cap;
   sa.n_slots = T;
   sa.q_len = n;
-  sa.n_split = ws.n_split;
+  sa.n_split = ws.n_partials;
   sa.t_pad = ws.t_pad;
   sa.layer_begin = st->layer_begin;
   sa.score_off = st->score_off;

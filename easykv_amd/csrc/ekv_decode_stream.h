@@ -126,7 +126,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         float mine = s[0];
 #pragma unroll
         for (int u = 1; u < kU; ++u) mine = (mu == u) ? s[u] : mine;
-        if (mu < kU && j0 + mu < t1) logit_out[(size_t)r * logit_stride + j0 + mu] = mine;
+        if (logit_out != nullptr && mu < kU && j0 + mu < t1) logit_out[(size_t)r * logit_stride + j0 + mu] = mine;
       }
       float mx = s[0];
 #pragma unroll

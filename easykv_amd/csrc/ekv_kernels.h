@@ -12,6 +12,8 @@ struct EkvWs {
   float* partials;  // [layer_count][Hq][q_len][n_split][D+2]   (m, l, o[D]) per key-range split
   float* tova_row;  // [layer_count][t_pad]   head-averaged last-query row (tova_head_mean)
   int32_t t_pad, n_split, rows_per_split;
+  int32_t n_partials;   // partials per query row the scorer folds (chunk kernels emit 2 per split)
+  int32_t qb_rows, n_qblocks;
   size_t bytes;
 };
 
@@ -29,6 +31,7 @@ struct EkvAttnArgs {
   const float* rope_cos;
   const float* rope_sin;
   int32_t n_q_heads, n_kv_heads, cap, n_slots, q_len, n_split, rows_per_split, t_pad, layer_begin, causal;
+  int32_t qb_rows, n_qblocks;  // chunk kernels: queries per query block, number of query blocks
   float sm_div;
 };
 
@@ -58,4 +61,5 @@ bool ekv_attn_decode_supported(int head_dim, int rep);
 bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict);
 hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, hipStream_t s);
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len);
+void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw);
 size_t ekv_score_lds_bytes(const EkvScoreArgs& a);
