@@ -1,0 +1,328 @@
+"""Host-side mirror of the reference's public surface for the budgeted-KV path.
+
+    from easykv_amd import enable_fixed_kv
+    enable_fixed_kv(model, tokenizer, mode='auto', stride=8)
+    text = model.easykv_generate(input_ids=ids, generation_config=dict(budget=2048, kv_policy='roco'))
+
+Same names, argument meaning, generation_config keys/defaults, kv_policy strings, return types and
+printed lines as the reference (easykv/easykv.py:199-210, :903-908).  What differs is WHERE the work
+happens: the reference asks the model for every layer's probability matrix and scores / selects /
+compacts in Python (easykv/easykv.py:264-362); here the driver only decides the per-forward
+:class:`StepPlan` and every layer's attention call runs the fused HIP step on a device-resident
+:class:`KVBank` — no attention map, no host sync, no K/V copy per step.
+
+Model contract (what ``self`` must provide; the reference's is SURVEY.md §8b):
+  * ``self.config.{num_hidden_layers, num_attention_heads[, num_key_value_heads][, head_dim | hidden_size]}``,
+    ``self.device`` (a GPU), ``self.tokenizer.{eos_token_id, decode}``;
+  * ``self(input_ids=, past_key_values=<BudgetedKVCache>, position_ids=, use_cache=True)`` returning an object
+    with ``.logits [1, n, V]``; inside, every attention layer calls
+    ``past_key_values.attend(layer_idx, q [1,Hq,n,D], k [1,H,n,D], v [1,H,n,D]) -> [1,Hq,n,D]`` with keys already
+    rotated by their TRUE positions (un-rotated when ``generation_config['streaming']``: the kernel then rotates at
+    read time by slot index, easykv/llama_patch.py:310-327).
+  ``easykv_amd.hf`` adapts HF transformers >= 5 Llama/Mistral models to this contract.
+"""
+from __future__ import annotations
+
+import functools
+import math
+import statistics
+import time
+from typing import List, Optional
+
+import torch
+
+from .engine import KVBank, StepPlan
+
+KNOWN_POLICIES = ("roco", "h2o_head", "tova", "recency", "random", "full")
+SCORED = ("roco", "h2o_head", "tova")
+PREFIX_BLOCK = 64   # queries per launch when the prefix must be scored (keep_attention)
+
+
+# ------------------------------------------------------------------------------------------------
+# budget geometry (easykv/easykv.py:385-392, :544-552, :773-780)
+# ------------------------------------------------------------------------------------------------
+def _idx_for(length: int, budget_p: int, stride: int) -> int:
+    return next(i for i in range(budget_p, -1, -1) if (length - i) % stride == 0)
+
+
+def geometry(mode: str, length: int, budget, stride: int):
+    """-> (budget', idx, r_idx).  ``idx`` = retained slots after the strided prefill, ``r_idx`` = dense prefix."""
+    if isinstance(budget, float):
+        budget_p = int(length * budget) + stride
+    else:
+        budget_p = budget + stride
+        if mode == "auto" and budget_p >= length:
+            budget_p -= stride
+    idx = _idx_for(length, budget_p, stride)
+    if mode == "encoding":      # largest r_idx < idx on the stride grid (:391-392)
+        r_idx = next(r for r in range(idx - 1, -1, -1) if (idx - r) % stride == 0)
+    else:                       # auto / ppl: smallest r_idx >= 1 (:551-552, :779-780)
+        r_idx = next(r for r in range(1, idx) if (idx - r) % stride == 0)
+    return budget_p, idx, r_idx
+
+
+# ------------------------------------------------------------------------------------------------
+# the cache object handed to the model
+# ------------------------------------------------------------------------------------------------
+class BudgetedKVCache:
+    """Device-resident budgeted cache of one sequence.  The driver sets :attr:`plan` before each model
+    forward; every attention layer then calls :meth:`attend`."""
+
+    def __init__(self, n_layers, n_q_heads, n_kv_heads, head_dim, cap, device, streaming=False, rope=None,
+                 record=False):
+        self.bank = KVBank(n_layers, n_q_heads, n_kv_heads, head_dim, cap, device=device)
+        self.plan = StepPlan(policy="full", phase="prefill", accumulate=False)
+        self.streaming = streaming
+        if streaming:
+            cos, sin = rope if rope is not None else rope_tables(cap, head_dim)
+            self.bank.set_rope(cos, sin)
+        self.record = record
+        self.evictions = []      # record=True: per forward with eviction: list over layers of int32 [H,k] (device)
+        self._cur = None
+        self.score_prefix = False
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.bank.n_slots[layer_idx]
+
+    def begin_forward(self, plan: StepPlan):
+        self.plan = plan
+        self._cur = [] if (self.record and plan.evict) else None
+        if self._cur is not None:
+            self.evictions.append(self._cur)
+
+    def attend(self, layer_idx: int, q, k, v):
+        """One layer of one forward: append + attention + score + select + compaction, all on device."""
+        plan = self.plan
+        n = q.shape[2]
+        q = q.to(torch.float16).contiguous()
+        k = k.to(torch.float16).contiguous()
+        v = v.to(torch.float16).contiguous()
+        if self.score_prefix and n > PREFIX_BLOCK:
+            # keep_attention: the dense prefix must also feed the score rows (easykv/easykv.py:173-186); it is
+            # processed in query blocks so the r x r probability matrix is never materialised
+            outs = []
+            for i0 in range(0, n, PREFIX_BLOCK):
+                o, _ = self.bank.attend(plan, q[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), k[:, :, i0:i0 + PREFIX_BLOCK].contiguous(),
+                                        v[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), layer_begin=layer_idx)
+                outs.append(o)
+            return torch.cat(outs, dim=2)
+        out, ids = self.bank.attend(plan, q, k, v, layer_begin=layer_idx)
+        if self._cur is not None and ids is not None:
+            self._cur.append(ids[0])
+        return out
+
+
+def rope_tables(seq_len: int, dim: int, base: float = 10000.0):
+    """fp32 cos/sin ``[seq_len, dim]`` with the HF layout ``cat(freqs, freqs)``."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+    freqs = torch.outer(torch.arange(seq_len, dtype=torch.float32), inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos(), emb.sin()
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler (easykv/easykv.py:115-134) — vocab-sized torch ops, not part of the KV path
+# ------------------------------------------------------------------------------------------------
+def logits_adapter(logits: torch.Tensor, temperature: float, top_p: float):
+    prob = torch.softmax(logits / temperature, dim=-1)
+    sorted_prob, order = torch.sort(prob, descending=True, dim=-1)
+    keep = (torch.cumsum(sorted_prob, dim=-1) - sorted_prob) <= top_p
+    sorted_prob = sorted_prob * keep
+    sorted_prob = sorted_prob / sorted_prob.sum(dim=-1, keepdim=True)
+    final = torch.zeros_like(prob).scatter(-1, order, sorted_prob)
+    return final, torch.softmax(logits, dim=-1)
+
+
+def _dims(self):
+    cfg = self.config
+    n_layers = cfg.num_hidden_layers
+    hq = cfg.num_attention_heads
+    h = getattr(cfg, "num_key_value_heads", None) or hq
+    d = getattr(cfg, "head_dim", None) or (cfg.hidden_size // hq)
+    return n_layers, hq, h, d
+
+
+# ------------------------------------------------------------------------------------------------
+# generate
+# ------------------------------------------------------------------------------------------------
+@torch.inference_mode()
+def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, report_decoding_latency: bool = False,
+             return_cache: bool = False):
+    cfg = generation_config
+    temperature = cfg.get("temperature", 1.0)
+    top_p = cfg.get("top_p", 1.0)
+    max_new_tokens = cfg.get("max_new_tokens", 1024)
+    budget = cfg.get("budget", 0.5)
+    policy = cfg.get("kv_policy", "recency")
+    sink = cfg.get("temp_length", 4)
+    recent_ratio = cfg.get("recent_ratio", 0.1)
+    keep_attention = cfg.get("keep_attention", False)
+    eos_token_ids = cfg.get("eos_token_ids", [self.tokenizer.eos_token_id])
+    streaming = cfg.get("streaming", False)
+    record = cfg.get("_record_evictions", False)      # test hook: keep the evicted ids of every forward
+    n_layers, hq, h, d = _dims(self)
+    dev = torch.device(self.device)
+    length = input_ids.shape[-1]
+    input_ids = input_ids.to(dev)
+    scored = policy in SCORED
+    evicting = policy in KNOWN_POLICIES and policy != "full"   # unknown strings evict nothing
+
+    if kv_mode == "auto":                                      # easykv/easykv.py:220-227
+        assert type(budget) == int
+        if budget > length:
+            kv_mode, budget = "decoding", budget - length
+        else:
+            kv_mode = "encoding_decoding"
+
+    def new_cache(cap):
+        return BudgetedKVCache(n_layers, hq, h, d, cap + 8, dev, streaming=streaming, record=record)
+
+    def forward(cache, ids, positions, plan):
+        plan.streaming = streaming
+        cache.begin_forward(plan)
+        return self(input_ids=ids, past_key_values=cache,
+                    position_ids=torch.as_tensor(positions, dtype=torch.long, device=dev).view(1, -1), use_cache=True)
+
+    def sample(logits_last):
+        prob, raw = logits_adapter(logits_last.float(), temperature, top_p)
+        return torch.multinomial(prob, num_samples=1)
+
+    # ---- single-token decode with eviction (decoding mode, and the tail of auto mode) ----------------------
+    def decode_loop(cache, logits_last, cur_pos, score_off, budget_d, whole_cache):
+        out_ids: List[int] = []
+        positions: List[int] = []
+        n = 0
+        while n < max_new_tokens:                               # :257 / :670
+            tok = sample(logits_last)
+            out_ids.append(int(tok[0, 0]))
+            n += 1
+            if out_ids[-1] in eos_token_ids:
+                break
+            t_now = cache.get_seq_length() + 1
+            evict = evicting and (whole_cache or (t_now - score_off) > budget_d)     # :303 / every step :708
+            plan = StepPlan(policy=policy, phase="decode", accumulate=scored, evict=evict, score_off=score_off, budget=budget_d)
+            positions.append(cur_pos)
+            if evict and policy in ("recency", "random"):
+                if whole_cache:                                 # :741-747
+                    if policy == "random":
+                        raise UnboundLocalError("auto mode + kv_policy='random' is broken in the reference (easykv/easykv.py:744)")
+                    plan.range_start = sink
+                else:                                           # :343-362: oldest / uniformly random generated slot
+                    e = 0 if policy == "recency" else int(torch.randint(len(positions), (1,)))
+                    positions.pop(e)
+                    plan.range_start = score_off + e
+            logits_last = forward(cache, tok.view(1, 1), [cur_pos], plan).logits[:, -1, :]
+            cur_pos += 1
+        return out_ids
+
+    # ---- dense prefix + strided chunks with eviction (encoding, auto, ppl) ---------------------------------
+    def prefill(cache, budget_p, idx, r_idx, tova_head_mean, keep_logits=False):
+        recent = int(budget_p * recent_ratio)                    # :394
+        cache.bank.state_init(idx + stride, 1 if keep_attention else 2, stride)       # :412-416
+        cache.score_prefix = keep_attention
+        # prefix [0, r_idx): dense causal; with keep_attention its probabilities seed S and Q (:396, :403-405)
+        plan = StepPlan(policy="roco" if keep_attention else "full", phase="prefill", accumulate=keep_attention,
+                        evict=False, stride=stride)
+        out = forward(cache, input_ids[:, :r_idx], list(range(r_idx)), plan)
+        cache.score_prefix = False
+        logits_last = out.logits[:, -1, :]
+        all_logits, all_ids = [], []
+        cur_pos = r_idx
+        for tok_i in range(r_idx, length, stride):                # :426
+            t_now = cache.get_seq_length() + stride
+            plan = StepPlan(policy=policy, phase="prefill", accumulate=scored and (t_now > idx or keep_attention),
+                            evict=evicting and t_now > idx, budget=budget_p, recent=recent, sink=sink, stride=stride,
+                            tova_head_mean=tova_head_mean)
+            if plan.evict and policy == "recency":
+                plan.range_start = sink                          # :491-493
+            elif plan.evict and policy == "random":              # :494-499
+                plan.range_start = int(torch.randint(idx, (1,)))
+            out = forward(cache, input_ids[:, tok_i:tok_i + stride], list(range(cur_pos, cur_pos + stride)), plan)
+            logits_last = out.logits[:, -1, :]
+            if keep_logits:
+                all_logits.append(out.logits[0])
+                all_ids.append(input_ids[0, tok_i:tok_i + stride])
+            cur_pos += stride
+        return logits_last, all_logits, all_ids
+
+    result = None
+    if kv_mode == "decoding":                                     # easykv/easykv.py:228-366
+        cap = length + (budget + 1 if evicting else max_new_tokens + 1)
+        cache = new_cache(cap)
+        out = forward(cache, input_ids, list(range(length)), StepPlan(policy="full", phase="prefill", accumulate=False))
+        cache.bank.state_init(budget + 1, 0)                       # :242-245
+        out_ids = decode_loop(cache, out.logits[:, -1, :], length, length, budget, False)
+        kept = cache.get_seq_length() - length
+        print(f"KV cache budget ratio: {kept / len(out_ids) * 100:.2f}%({kept}/{len(out_ids)})")
+        result = self.tokenizer.decode(out_ids, skip_special_tokens=True).strip()
+
+    elif kv_mode == "encoding":                                   # :367-529
+        full = (type(budget) == float and budget >= 1.0) or (type(budget) == int and budget >= length)
+        if full:
+            cache = new_cache(length + max_new_tokens)
+            logits_last = forward(cache, input_ids, list(range(length)),
+                                  StepPlan(policy="full", phase="prefill", accumulate=False)).logits[:, -1, :]
+        else:
+            budget_p, idx, r_idx = geometry("encoding", length, budget, stride)
+            cache = new_cache(idx + stride + max_new_tokens)
+            logits_last, _, _ = prefill(cache, budget_p, idx, r_idx, True)
+        kept = cache.get_seq_length()
+        print(f"KV cache budget ratio: {kept / length * 100:.2f}%({kept}/{length})")
+        out_ids, times, n, cur_pos = [], [], 0, length
+        while n < max_new_tokens:                                  # :508-526 plain decode, no eviction
+            tok = sample(logits_last)
+            out_ids.append(int(tok[0, 0]))
+            n += 1
+            if out_ids[-1] in eos_token_ids:
+                break
+            t0 = time.time()
+            logits_last = forward(cache, tok.view(1, 1), [cur_pos],
+                                  StepPlan(policy="full", phase="decode", accumulate=False)).logits[:, -1, :]
+            times.append(time.time() - t0)
+            cur_pos += 1
+        result = self.tokenizer.decode(out_ids, skip_special_tokens=True).strip()
+        if report_decoding_latency and len(times) > 1:
+            print(f"Per-step decoding latency: {statistics.mean(times[1:]):.3f}")
+
+    elif kv_mode == "encoding_decoding":                          # :530-753
+        assert type(budget) == int and budget <= length
+        white_lst = ["random", "recency", "tova", "roco"]
+        assert policy in white_lst, f"mode must be within {white_lst}, get {policy} instead"
+        assert stride > 1, "auto mode needs stride > 1 (the reference asserts at easykv/easykv.py:666-669)"
+        budget_p, idx, r_idx = geometry("auto", length, budget, stride)
+        cache = new_cache(idx + stride + 1)
+        logits_last, _, _ = prefill(cache, budget_p, idx, r_idx, False)
+        # the score rows keep their first idx+1 columns (:666-669); the decode rules then run over the whole cache
+        out_ids = decode_loop(cache, logits_last, length, 0, budget_p, True)
+        size = cache.get_seq_length()
+        print(f"KV Cache Budget ratio {size / (length + len(out_ids)) * 100:.2f}%[{size}/({length}+{len(out_ids)})]")
+        result = self.tokenizer.decode(out_ids, skip_special_tokens=True).strip()
+
+    elif kv_mode == "ppl":                                        # :754-901
+        ce = torch.nn.CrossEntropyLoss(reduction="none")
+        if budget >= 1.0:     # NB: like the reference, ANY int budget takes this branch (:759); pass a ratio to evict
+            cache = new_cache(length)
+            out = forward(cache, input_ids, list(range(length)), StepPlan(policy="full", phase="prefill", accumulate=False))
+            lp = ce(out.logits[0, :-1].float(), input_ids[0, 1:]).cpu().numpy().tolist()
+            result = math.exp(statistics.mean(lp))
+        else:
+            budget_p, idx, r_idx = geometry("ppl", length, budget, stride)
+            cache = new_cache(idx + stride)
+            _, all_logits, all_ids = prefill(cache, budget_p, idx, r_idx, True, keep_logits=True)
+            kept = cache.get_seq_length()
+            print(f"KV cache budget ratio: {kept / length * 100:.2f}%({kept}/{length})")
+            ids_cat, log_cat = torch.cat(all_ids), torch.cat(all_logits, dim=0)
+            assert ids_cat.shape[0] == log_cat.shape[0]
+            lp = ce(log_cat[:-1].float(), ids_cat[1:]).cpu().numpy().tolist()
+            result = math.exp(statistics.mean(lp))
+    else:
+        raise ValueError(f"unknown kv_mode {kv_mode!r}")
+    return (result, cache) if return_cache else result
+
+
+def enable_fixed_kv(model, tokenizer, mode, stride=1, verbose=False):
+    """easykv/easykv.py:903-908."""
+    model.tokenizer = tokenizer
+    model.easykv_generate = functools.partial(generate, self=model, kv_mode=mode, stride=stride, report_decoding_latency=verbose)
+    model.easykv_ppl = functools.partial(generate, self=model, kv_mode="ppl", stride=stride)
+    print(f"Fixed KV Cache for {mode} enabled")
