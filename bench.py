@@ -97,16 +97,11 @@ def main():
     ap.add_argument("--split-kernels", action="store_true", help="force the two-kernel path (attention + score/select)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from easykv_amd import dist as DS
+    rank, local_rank, world = DS.init("nccl")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    shard = DS.LayerShard(rank, world, args.layers * world)   # weak scaling: every rank owns a block of `layers` layers
 
     from easykv_amd import KVBank, StepPlan
 
@@ -163,29 +158,17 @@ def main():
             else:
                 bank.attend(*a, **kw)
         if world > 1 and not args.no_handoff:   # pipeline hand-off of the stage output (north star)
-            reqs = [dist.isend(hidden, (rank + 1) % world), dist.irecv(hidden_in, (rank - 1) % world)]
-            for r in reqs:
-                r.wait()
+            DS.ring_handoff(hidden, hidden_in, shard)
 
     for i in range(args.warmup):
         step(i)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
+    DS.barrier(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i, i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    DS.barrier(dev)
+    elapsed = DS.max_over_ranks(time.perf_counter() - t0, dev)
 
     assert all(n == budget for n in bank.n_slots), bank.n_slots
     if rank == 0:
@@ -195,7 +178,7 @@ def main():
         t_attn = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3
         cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={L} Hq={Hq} H={H} D={D} budget={budget} "
                            f"T={T} kv_policy={args.policy} (Llama2-7B shape, budget=50% of S=4096)",
-               "layers_per_launch": lpl, "layers_per_rank": L, "n_split": n_split, "fused": fused,
+               "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [shard.begin, shard.end], "n_split": n_split, "fused": fused,
                "handoff": (world > 1 and not args.no_handoff)}
         line = {
             "metric": "decode_tokens_per_sec", "value": world * args.steps / elapsed, "unit": "tokens/s",
@@ -222,8 +205,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, budget, args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco")
         print(json.dumps(line))
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        DS.barrier(dev)
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

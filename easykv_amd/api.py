@@ -55,9 +55,9 @@ def geometry(mode: str, length: int, budget, stride: int):
             budget_p -= stride
     idx = _idx_for(length, budget_p, stride)
     if mode == "encoding":      # largest r_idx < idx on the stride grid (:391-392)
-        r_idx = next(r for r in range(idx - 1, -1, -1) if (idx - r) % stride == 0)
+        r_idx = next((r for r in range(idx - 1, -1, -1) if (idx - r) % stride == 0), None)
     else:                       # auto / ppl: smallest r_idx >= 1 (:551-552, :779-780)
-        r_idx = next(r for r in range(1, idx) if (idx - r) % stride == 0)
+        r_idx = next((r for r in range(1, idx) if (idx - r) % stride == 0), None)
     return budget_p, idx, r_idx
 
 

@@ -1,0 +1,86 @@
+"""One process per GPU: layer-block ownership and the pipeline hand-off.
+
+Eviction state and decisions are per (layer, KV head), so a layer's K/V rows, slot map and score rows stay on
+the GPU that owns the layer; the only thing that ever crosses xGMI is the stage output ``[1, q, hidden]`` fp16
+(8 KB per decode token for Llama2-7B) between neighbouring stages — a point-to-point send/recv over one link,
+no all-reduce / all-gather anywhere on the path.  ``torch.distributed`` backend ``nccl`` is RCCL on ROCm; the
+same code runs on ``gloo`` for the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class LayerShard:
+    rank: int
+    world: int
+    n_layers: int
+
+    @property
+    def begin(self) -> int:
+        return (self.n_layers * self.rank) // self.world
+
+    @property
+    def end(self) -> int:
+        return (self.n_layers * (self.rank + 1)) // self.world
+
+    @property
+    def count(self) -> int:
+        return self.end - self.begin
+
+    @property
+    def next_rank(self) -> int:
+        return (self.rank + 1) % self.world
+
+    @property
+    def prev_rank(self) -> int:
+        return (self.rank - 1) % self.world
+
+
+def init(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env (torch.distributed.run). Returns (rank, local, world)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, local, world
+
+
+def ring_handoff(send: torch.Tensor, recv: torch.Tensor, shard: LayerShard):
+    """Stage output to the next stage, stage input from the previous one (one P2P pair per step)."""
+    if shard.world == 1:
+        recv.copy_(send)
+        return
+    ops = [dist.P2POp(dist.isend, send, shard.next_rank), dist.P2POp(dist.irecv, recv, shard.prev_rank)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
+def barrier(device=None):
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,71 @@
+"""CPU-side checks (no GPU): host geometry vs the oracle and the README's known answers, the C-ABI library loads
+and exports every symbol include/easykv_hip.h declares, and the product path fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import easykv_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_geometry_matches_oracle_and_readme():
+    from easykv_amd.api import geometry
+    for length in (100, 101, 512, 4096, 5144, 9994, 10253):
+        for stride in (1, 4, 7, 8, 24, 96):
+            for budget in (0.3, 0.5, 40, 2048):
+                if isinstance(budget, int) and budget >= length:
+                    continue
+                assert geometry("encoding", length, budget, stride) == O.geometry_encoding(length, budget, stride)
+                assert geometry("ppl", length, budget, stride) == O.geometry_ppl(length, budget, stride)
+                if isinstance(budget, int) and stride > 1:
+                    assert geometry("auto", length, budget, stride) == O.geometry_auto(length, budget, stride)
+    # retained slots printed in the reference's README (README.md:153, :211, :314)
+    assert geometry("encoding", 5144, 0.5, 24)[1] == 2576
+    assert geometry("encoding", 9994, 0.5, 96)[1] == 5002
+    assert geometry("ppl", 10253, 0.5, 96)[1] == 5165
+
+
+def test_abi_exports_every_declared_symbol():
+    from easykv_amd import _build, _lib
+    header = open(os.path.join(ROOT, "include", "easykv_hip.h")).read()
+    declared = set(re.findall(r"\b(ekv_[a-z_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    if not os.path.exists(_build.LIB):
+        _build.build_lib()
+    lib = _lib.load()
+    raw = ctypes.CDLL(_build.LIB)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.ekv_abi_version() == 1
+    assert b"workspace" in lib.ekv_strerror(-3)
+    # argument checking happens before any device access: callable without a GPU
+    assert lib.ekv_workspace_bytes(None, None) == 0
+    assert lib.ekv_bank_reset(None, None) == -1
+
+
+def test_struct_layout_matches_header():
+    from easykv_amd._lib import Bank, Step
+    assert ctypes.sizeof(Bank) == 6 * 8 + 5 * 4 + 4      # 6 pointers, 5 int32, tail padding
+    assert ctypes.sizeof(Step) == 18 * 4 + 4 * 4
+    header = open(os.path.join(ROOT, "include", "easykv_hip.h")).read()
+    body = header[header.index("typedef struct ekv_step {"):header.index("} ekv_step;")]
+    names = re.findall(r"\b([a-z_0-9]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert names == [n for n, _ in Step._fields_]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_path_has_no_cpu_fallback():
+    import easykv_amd
+    with pytest.raises(Exception) as e:
+        easykv_amd.KVBank(1, 4, 4, 32, 64, device="cpu")
+    assert "no CPU fallback" in str(e.value)
+    # nothing under easykv_amd/ may import the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "easykv_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
