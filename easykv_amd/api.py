@@ -66,7 +66,11 @@ def geometry(mode: str, length: int, budget, stride: int):
 # ------------------------------------------------------------------------------------------------
 class BudgetedKVCache:
     """Device-resident budgeted cache of one sequence.  The driver sets :attr:`plan` before each model
-    forward; every attention layer then calls :meth:`attend`."""
+    forward; every attention layer then calls :meth:`attend`.  It also duck-types the two ``Cache`` methods HF
+    transformers >= 5 calls on ``past_key_values`` (``update`` hands the new rows straight back: the bank appends them
+    inside :meth:`attend`)."""
+
+    current = None     # the cache of the forward in flight (set by begin_forward; read by easykv_amd.hf)
 
     def __init__(self, n_layers, n_q_heads, n_kv_heads, head_dim, cap, device, streaming=False, rope=None,
                  record=False):
@@ -74,6 +78,8 @@ class BudgetedKVCache:
         self.plan = StepPlan(policy="full", phase="prefill", accumulate=False)
         self.streaming = streaming
         if streaming:
+            if getattr(self, "_hf", False):
+                raise NotImplementedError("streaming=True needs un-rotated keys; the HF adapter hands over rotated ones")
             cos, sin = rope if rope is not None else rope_tables(cap, head_dim)
             self.bank.set_rope(cos, sin)
         self.record = record
@@ -84,7 +90,11 @@ class BudgetedKVCache:
     def get_seq_length(self, layer_idx: int = 0) -> int:
         return self.bank.n_slots[layer_idx]
 
+    def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
+        return key_states, value_states
+
     def begin_forward(self, plan: StepPlan):
+        BudgetedKVCache.current = self
         self.plan = plan
         self._cur = [] if (self.record and plan.evict) else None
         if self._cur is not None:
@@ -250,7 +260,8 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
         cap = length + (budget + 1 if evicting else max_new_tokens + 1)
         cache = new_cache(cap)
         out = forward(cache, input_ids, list(range(length)), StepPlan(policy="full", phase="prefill", accumulate=False))
-        cache.bank.state_init(budget + 1, 0)                       # :242-245
+        if evicting and scored:
+            cache.bank.state_init(budget + 1, 0)                   # :242-245
         out_ids = decode_loop(cache, out.logits[:, -1, :], length, length, budget, False)
         kept = cache.get_seq_length() - length
         print(f"KV cache budget ratio: {kept / len(out_ids) * 100:.2f}%({kept}/{len(out_ids)})")

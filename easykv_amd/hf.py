@@ -1,0 +1,55 @@
+"""HF transformers >= 5 seam for the budgeted-KV path.
+
+The reference monkey-patches ``LlamaAttention.forward`` per instance (easykv/utils.py:5-51, easykv/easykv.py:253-256),
+which cannot bind to transformers >= 5 (different forward signature, no ``self.rotary_emb``).  The equivalent seam is
+``AttentionInterface``: the stock attention module projects and rotates q/k/v, calls ``past_key_values.update()`` (which
+here just hands the NEW rows back) and then the registered attention function, which runs the fused HIP step on the
+:class:`~easykv_amd.api.BudgetedKVCache` of the forward in flight.  No attention mask is built (the implementation is
+not in the mask registry) and no probability matrix is ever returned.
+
+    model = AutoModelForCausalLM.from_pretrained(path, torch_dtype=torch.float16).cuda()
+    easykv_amd.hf.patch_model(model)
+    easykv_amd.enable_fixed_kv(model, tokenizer, mode='auto', stride=8)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import api
+
+IMPL = "easykv_amd"
+_registered = False
+
+
+def _easykv_attention(module, query, key, value, attention_mask=None, dropout=0.0, scaling=None, **kwargs):
+    cache = api.BudgetedKVCache.current
+    if cache is None:
+        raise RuntimeError("easykv_amd attention called outside easykv_generate(): no BudgetedKVCache is active")
+    d = query.shape[-1]
+    if scaling is not None and abs(scaling * (d ** 0.5) - 1.0) > 1e-3:
+        raise ValueError("easykv_amd attention supports the standard 1/sqrt(head_dim) scaling only")
+    out = cache.attend(module.layer_idx, query, key, value)        # [1, Hq, n, D] fp16
+    return out.transpose(1, 2).to(query.dtype), None
+
+
+def register():
+    global _registered
+    if not _registered:
+        from transformers import AttentionInterface
+        AttentionInterface.register(IMPL, _easykv_attention)
+        _registered = True
+
+
+def patch_model(model):
+    """Route every attention layer of a HF Llama/Mistral-style model through the HIP path."""
+    register()
+    cfg = model.config
+    if getattr(cfg, "sliding_window", None) and getattr(cfg, "model_type", "") == "mistral":
+        # the reference ignores Mistral's sliding window as well (easykv/mistral_patch.py:90-186)
+        pass
+    cfg._attn_implementation = IMPL
+    for sub in model.modules():
+        sub_cfg = getattr(sub, "config", None)
+        if sub_cfg is not None and hasattr(sub_cfg, "_attn_implementation"):
+            sub_cfg._attn_implementation = IMPL
+    return model

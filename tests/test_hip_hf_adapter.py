@@ -1,0 +1,73 @@
+"""HF transformers >= 5 seam: a tiny random-init Llama routed through the HIP path (easykv_amd.hf)."""
+import contextlib
+import io
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _Tok:
+    eos_token_id = -1
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(i) for i in ids)
+
+
+def _tiny(seed=0, kv_heads=2):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(seed)
+    cfg = LlamaConfig(vocab_size=97, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=kv_heads, head_dim=32, max_position_embeddings=512, attn_implementation="eager")
+    return LlamaForCausalLM(cfg).half().cuda().eval()
+
+
+def test_full_budget_matches_hf_eager_logits_and_greedy_tokens():
+    import easykv_amd
+    from easykv_amd import hf
+    model = _tiny()
+    ids = torch.randint(0, 97, (1, 40), device="cuda")
+    with torch.inference_mode():
+        ref_logits = model(input_ids=ids).logits.float()
+        ref_tokens = model.generate(ids, max_new_tokens=8, do_sample=False)[0, 40:].tolist()
+    hf.patch_model(model)
+    easykv_amd.enable_fixed_kv(model, _Tok(), mode="decoding", stride=1)
+    # prefill through the chunk kernel: logits of the patched forward
+    cache = easykv_amd.BudgetedKVCache(2, 4, 2, 32, 64, torch.device("cuda"))
+    cache.begin_forward(easykv_amd.StepPlan(policy="full", phase="prefill", accumulate=False))
+    with torch.inference_mode():
+        got = model(input_ids=ids, past_key_values=cache, position_ids=torch.arange(40, device="cuda").view(1, -1), use_cache=True).logits.float()
+    assert torch.allclose(got, ref_logits, atol=3e-2, rtol=3e-2), float((got - ref_logits).abs().max())
+    # greedy decode with no eviction ('full'): same tokens as HF's own generate
+    out = model.easykv_generate(input_ids=ids, generation_config=dict(temperature=1e-6, kv_policy="full", budget=200, max_new_tokens=8,
+                                                                      eos_token_ids=[-1]))
+    assert [int(t) for t in out.split()] == ref_tokens
+
+
+@pytest.mark.parametrize("mode,cfg", [
+    ("decoding", dict(budget=32, kv_policy="roco", max_new_tokens=48)),
+    ("encoding", dict(budget=0.5, kv_policy="h2o_head", max_new_tokens=4)),
+    ("auto", dict(budget=48, kv_policy="roco", max_new_tokens=8, recent_ratio=0.3)),
+])
+def test_eviction_modes_run_on_a_real_hf_model(mode, cfg):
+    import easykv_amd
+    from easykv_amd import hf
+    model = hf.patch_model(_tiny(1))
+    stride = 1 if mode == "decoding" else 8
+    easykv_amd.enable_fixed_kv(model, _Tok(), mode=mode, stride=stride)
+    ids = torch.randint(0, 97, (1, 120 if mode != "decoding" else 16), device="cuda")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out, cache = model.easykv_generate(input_ids=ids, generation_config=dict(cfg, eos_token_ids=[-1], temperature=1e-6), return_cache=True)
+    line = buf.getvalue()
+    assert "udget ratio" in line
+    assert len(out.split()) == cfg["max_new_tokens"]
+    if mode == "decoding":
+        assert cache.get_seq_length() == 16 + 32
+    elif mode == "encoding":
+        _, idx, _ = easykv_amd.geometry("encoding", 120, 0.5, 8)
+        assert cache.get_seq_length() == idx + cfg["max_new_tokens"]   # N forwards: the last sampled token is fed too
+    else:
+        _, idx, _ = easykv_amd.geometry("auto", 120, 48, 8)
+        assert cache.get_seq_length() == idx
