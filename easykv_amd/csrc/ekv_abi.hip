@@ -1,5 +1,6 @@
 // C ABI of the MI355X-native budgeted-KV attention path (see include/easykv_hip.h) + utility kernels.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ekv_common.h"
 #include "ekv_kernels.h"
@@ -168,7 +169,7 @@ int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, in
   const EkvWs ws = ekv_plan_workspace(bank, st, nullptr);
   *n_split = ws.n_split;
   *fused = (st->q_len == 1 && st->phases == 0 && ws.n_split == 1 &&
-            ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, st->n_evict))
+            ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, st->n_evict, bank->cap))
                ? 1 : 0;
   return EKV_OK;
 }
@@ -245,6 +246,10 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.t_pad = ws.t_pad;
   aa.layer_begin = st->layer_begin;
   aa.causal = st->causal;
+  {
+    static const int stagger_env = getenv("EKV_STAGGER") ? atoi(getenv("EKV_STAGGER")) : 0;
+    aa.stagger = stagger_env;
+  }
   aa.qb_rows = ws.qb_rows;
   aa.n_qblocks = ws.n_qblocks;
   aa.sm_div = st->sm_div;
@@ -284,7 +289,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
 
   // whole decode step in one launch when no head has to be split
   if (n == 1 && st->phases == 0 && ws.n_split == 1 &&
-      ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, st->n_evict)) {
+      ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, st->n_evict, bank->cap)) {
     return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
 

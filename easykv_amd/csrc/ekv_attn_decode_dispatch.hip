@@ -40,8 +40,9 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 }
 
 // The whole decode step in one launch: possible when a head is not split, at most one victim, and the row fits.
-bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict) {
-  if (!ekv_attn_decode_supported(head_dim, rep) || n_evict > 1 || n_slots > 256 * 24) return false;
+bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap) {
+  // (the slot map and the score rows are fetched 16 bytes at a time: rows must be 16-byte aligned)
+  if (!ekv_attn_decode_supported(head_dim, rep) || n_evict > 1 || n_slots > 256 * 24 || (cap & 3) != 0 || cap < 16) return false;
   const bool rope = false;
   size_t lds = 1 << 30;
   switch (head_dim) {

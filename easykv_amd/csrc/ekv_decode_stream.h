@@ -17,13 +17,14 @@ struct EkvDecodeGeom {
   static constexpr int LPR = D / 8;   // lanes per row
   static constexpr int G = 64 / LPR;  // rows per wave-load
   static constexpr int RW = G * kU;   // rows per wave per iteration
-  static constexpr int NP = kNW * G;  // lane-group partials per workgroup
+  static constexpr int NP = kNW;      // partials per workgroup (lane groups are combined in-wave)
   static constexpr int PS = D + 2;    // (m, l, o[D])
 };
 
-// Streams positions [t0, t1) of KV head h.  s_slot holds slot_of_pos[t0..t1).  Logits (q.k / sm_div) go to
-// `logit_out` (+ row stride `logit_stride` per query head): global workspace or LDS.
-template <int D, int REP, bool ROPE>
+// Streams positions [t0, t1) of KV head h.  SLOT_LDS: s_slot holds slot_of_pos[t0..t1) in LDS; otherwise s_slot is
+// the head's row of the global slot map (t0 must be a multiple of 8) and the 8 indices of a lane group are fetched
+// one iteration ahead.  Logits (q.k / sm_div) go to `logit_out` (+ `logit_stride` per query head): workspace or LDS.
+template <int D, int REP, bool ROPE, bool SLOT_LDS>
 __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
                                                   int logit_stride, int t0, int t1, int ll, int h, size_t head_row,
                                                   float (&m)[REP], float (&l)[REP], float (&o)[REP][8]) {
@@ -62,8 +63,9 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
 
   const __half* k_new_row = a.k_new + ((size_t)ll * a.n_kv_heads + h) * D;
   const __half* v_new_row = a.v_new + ((size_t)ll * a.n_kv_heads + h) * D;
+  const int slot_base = SLOT_LDS ? t0 : 0;   // index origin of s_slot
   if (t_new >= t0 && t_new < t1 && wave == 0 && grp == 0) {  // append: the new row goes into the recycled slot
-    const size_t off = (head_row + s_slot[t_new - t0]) * D;
+    const size_t off = (head_row + s_slot[t_new - slot_base]) * D;
     reinterpret_cast<uint4*>(a.k_w + off)[sub] = reinterpret_cast<const uint4*>(k_new_row)[sub];
     reinterpret_cast<uint4*>(a.v_w + off)[sub] = reinterpret_cast<const uint4*>(v_new_row)[sub];
   }
@@ -76,14 +78,29 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     for (int i = 0; i < 8; ++i) o[r][i] = 0.f;
   }
 
+  static_assert(kU == 8, "index prefetch assumes 8 rows per lane group");
+  const int last_slot = s_slot[t1 - 1 - slot_base];
+  const int idx_cap = (a.cap - 8) & ~7;   // prefetches past t1 stay inside the head's map row (values unused)
+  uint4 ia = {0, 0, 0, 0}, ib = {0, 0, 0, 0};   // !SLOT_LDS: slot indices of rows j0..j0+7 of the next iteration
+  if (!SLOT_LDS && t0 + wave * RW < t1) {
+    const uint4* ip = reinterpret_cast<const uint4*>(s_slot + min(t0 + wave * RW + grp * kU, idx_cap));
+    ia = ip[0];
+    ib = ip[1];
+  }
   for (int base = t0 + wave * RW; base < t1; base += kNW * RW) {
     uint4 kr[kU], vr[kU];
     const int j0 = base + grp * kU;
+    const int cur[8] = {(int)ia.x, (int)ia.y, (int)ia.z, (int)ia.w, (int)ib.x, (int)ib.y, (int)ib.z, (int)ib.w};
+    if (!SLOT_LDS && base + kNW * RW < t1) {     // next iteration's indices (the map row has >= t_pad entries)
+      const uint4* ip = reinterpret_cast<const uint4*>(s_slot + min(j0 + kNW * RW, idx_cap));
+      ia = ip[0];
+      ib = ip[1];
+    }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int j = j0 + u;
       const int jj = j < t1 ? j : t1 - 1;
-      const int row = s_slot[jj - t0];
+      const int row = SLOT_LDS ? s_slot[jj - t0] : (j < t1 ? cur[u] : last_slot);
       // the appended position is read from k_new/v_new (pointer select, no branch in the hot loop)
       const bool is_new = jj == t_new;
       const __half* kp = is_new ? k_new_row : a.k + (head_row + row) * D;
@@ -148,16 +165,38 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   }
 }
 
-// Lane-group partials -> LDS (call, then __syncthreads(), then ekv_decode_reduce).
+// Combine the G lane groups of a wave (flash-decoding merge over lanes LPR, 2*LPR, ... apart); afterwards every lane
+// holds the wave's (m, l, o) for its 8-wide slice of head_dim.
+template <int D, int REP>
+__device__ __forceinline__ void ekv_decode_wave_combine(float (&m)[REP], float (&l)[REP], float (&o)[REP][8]) {
+  using Gm = EkvDecodeGeom<D>;
+#pragma unroll
+  for (int off = Gm::LPR; off < 64; off <<= 1) {
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      const float mo = __shfl_xor(m[r], off, 64), lo = __shfl_xor(l[r], off, 64);
+      const float mn = fmaxf(m[r], mo);
+      const float wa = (m[r] == EKV_NEG_INF) ? 0.f : exp2f((m[r] - mn) * EKV_LOG2E);
+      const float wb = (mo == EKV_NEG_INF) ? 0.f : exp2f((mo - mn) * EKV_LOG2E);
+      l[r] = l[r] * wa + lo * wb;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[r][i] = o[r][i] * wa + __shfl_xor(o[r][i], off, 64) * wb;
+      m[r] = mn;
+    }
+  }
+}
+
+// Wave partials -> LDS (call after ekv_decode_wave_combine, then __syncthreads(), then ekv_decode_reduce).
 template <int D, int REP>
 __device__ __forceinline__ void ekv_decode_stash(float* s_part, const float (&m)[REP], const float (&l)[REP],
                                                  const float (&o)[REP][8]) {
   using Gm = EkvDecodeGeom<D>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % Gm::LPR, grp = lane / Gm::LPR;
+  if (grp != 0) return;
 #pragma unroll
   for (int r = 0; r < REP; ++r) {
-    float* p = s_part + ((size_t)(wave * Gm::G + grp) * REP + r) * Gm::PS;
+    float* p = s_part + ((size_t)wave * REP + r) * Gm::PS;
     if (sub == 0) {
       p[0] = m[r];
       p[1] = l[r];
@@ -167,14 +206,16 @@ __device__ __forceinline__ void ekv_decode_stash(float* s_part, const float (&m)
   }
 }
 
-// Combined (max, sum, o[d]) of query head r over the workgroup's lane-group partials.
+// Combined (max, sum, o[d]) of query head r over the workgroup's wave partials.
 template <int D, int REP>
 __device__ __forceinline__ void ekv_decode_reduce(const float* s_part, int r, int d, float& mm, float& ls, float& os) {
   using Gm = EkvDecodeGeom<D>;
   mm = EKV_NEG_INF;
+#pragma unroll
   for (int i = 0; i < Gm::NP; ++i) mm = fmaxf(mm, s_part[((size_t)i * REP + r) * Gm::PS]);
   ls = 0.f;
   os = 0.f;
+#pragma unroll
   for (int i = 0; i < Gm::NP; ++i) {
     const float* p = s_part + ((size_t)i * REP + r) * Gm::PS;
     const float w = (p[0] == EKV_NEG_INF) ? 0.f : exp2f((p[0] - mm) * EKV_LOG2E);

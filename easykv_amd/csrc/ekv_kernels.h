@@ -32,6 +32,7 @@ struct EkvAttnArgs {
   const float* rope_sin;
   int32_t n_q_heads, n_kv_heads, cap, n_slots, q_len, n_split, rows_per_split, t_pad, layer_begin, causal;
   int32_t qb_rows, n_qblocks;  // chunk kernels: queries per query block, number of query blocks
+  int32_t stagger;             // fused decode: start delay (x s_sleep 64) per co-resident workgroup slot
   float sm_div;
 };
 
@@ -58,7 +59,7 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 bool ekv_attn_decode_supported(int head_dim, int rep);
-bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict);
+bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap);
 hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, hipStream_t s);
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len);
 void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw);

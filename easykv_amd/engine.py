@@ -51,6 +51,7 @@ class KVBank:
         if dev.type != "cuda":
             raise _lib.EkvError("KVBank needs a GPU device; the product path has no CPU fallback")
         self.device = dev
+        cap = (cap + 63) // 64 * 64     # rows of the slot map / score rows stay 16-byte aligned (fused kernel, LDS-DMA)
         self.n_layers, self.n_q_heads, self.n_kv_heads, self.head_dim, self.cap = n_layers, n_q_heads, n_kv_heads, head_dim, cap
         self.k = torch.empty(n_layers, n_kv_heads, cap, head_dim, dtype=torch.float16, device=dev)
         self.v = torch.empty_like(self.k)

@@ -1,0 +1,70 @@
+"""Boundary kernels of the C ABI: ordered gather (the HF legacy-tuple view), row import, and the reference-shaped
+in-place compaction (easykv/easykv.py:56-82) — checked against the oracle's order-preserving delete."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("D", [32, 64, 128])
+@pytest.mark.parametrize("k", [1, 7, 96])
+def test_compact_inplace_equals_reference_delete(D, k):
+    from easykv_amd import KVBank
+    from oracle import easykv_oracle as O
+    L, H, T = 2, 3, 700
+    g = torch.Generator().manual_seed(D + k)
+    kk = torch.randn(L, H, T, D, generator=g).half()
+    vv = torch.randn(L, H, T, D, generator=g).half()
+    ids = torch.stack([torch.stack([torch.randperm(T, generator=g)[:k].sort()[0] for _ in range(H)]) for _ in range(L)])
+    bank = KVBank(L, H, H, D, cap=T)
+    bank.load_rows(kk.cuda(), vv.cuda())
+    bank.compact_inplace(ids.int().cuda())
+    k_got, v_got = bank.ordered_kv()
+    for l in range(L):
+        k_ref = O.drop_kv_slots(kk[l:l + 1].float(), ids[l])
+        v_ref = O.drop_kv_slots(vv[l:l + 1].float(), ids[l])
+        assert torch.equal(k_got[l].float().cpu(), k_ref[0])
+        assert torch.equal(v_got[l].float().cpu(), v_ref[0])
+    assert bank.n_slots == [T - k] * L
+
+
+def test_ordered_view_after_recycling_equals_reference_cache():
+    """After many evictions rows are physically scrambled; the ordered view must equal the cache the reference would
+    hold (birth order), bit for bit."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    L, Hq, H, D, P, budget, steps = 1, 4, 4, 64, 8, 40, 120
+    g = torch.Generator().manual_seed(3)
+    qs = torch.randn(L, Hq, P + steps, D, generator=g).half()
+    ks = torch.randn(L, H, P + steps, D, generator=g).half()
+    vs = torch.randn(L, H, P + steps, D, generator=g).half()
+    bank = KVBank(L, Hq, H, D, cap=P + budget + 1)
+    bank.load_rows(ks[:, :, :P].cuda(), vs[:, :, :P].cuda())
+    bank.state_init(budget + 1, 0)
+    st = O.LayerState(k=ks[:, :, :P].float(), v=vs[:, :, :P].float())
+    st.s, st.q, st.c = O.init_state_decoding((H,), budget)
+    for i in range(steps):
+        t = P + i
+        evict = (bank.n_slots[0] + 1 - P) > budget
+        bank.attend(StepPlan(policy="h2o_head", phase="decode", evict=evict, score_off=P, budget=budget),
+                    qs[:, :, t:t + 1].cuda().contiguous(), ks[:, :, t:t + 1].cuda().contiguous(), vs[:, :, t:t + 1].cuda().contiguous())
+        O.layer_step(st, qs[:, :, t:t + 1].float(), ks[:, :, t:t + 1].float(), vs[:, :, t:t + 1].float(),
+                     O.StepPlan(policy="h2o_head", phase="decode", evict=evict, score_off=P, budget=budget))
+    k_got, v_got = bank.ordered_kv()
+    assert torch.equal(k_got.float().cpu(), st.k) and torch.equal(v_got.float().cpu(), st.v)
+    # the slot map is a permutation of the physical rows
+    m = bank.slot_of_pos[0].cpu().numpy()
+    for h in range(H):
+        assert np.array_equal(np.sort(m[h]), np.arange(bank.cap))
+
+
+def test_argument_errors_are_reported():
+    from easykv_amd import KVBank, StepPlan
+    bank = KVBank(1, 4, 4, 32, cap=64)
+    q = torch.zeros(1, 4, 1, 32, dtype=torch.float16, device="cuda")
+    bank.n_slots[0] = bank.cap          # no room for the new row
+    with pytest.raises(ValueError):
+        bank.attend(StepPlan(policy="full"), q, q, q)
+    with pytest.raises(Exception):
+        KVBank(1, 4, 4, 48, cap=64)     # unsupported head_dim
