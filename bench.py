@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-handoff", action="store_true")
     ap.add_argument("--split-kernels", action="store_true", help="force the two-kernel path (attention + score/select)")
+    ap.add_argument("--graph", action="store_true", help="capture one step (all launches) in a hipGraph and replay it")
     args = ap.parse_args()
 
     from easykv_amd import dist as DS
@@ -163,12 +164,31 @@ def main():
     for i in range(args.warmup):
         step(i)
 
+    graph = None
+    if args.graph:   # launch-bound regimes (per-layer launches): replay the step as one hipGraph
+        sq, sk, sv = qs[0].clone(), ks[0].clone(), vs[0].clone()
+        qs_src, ks_src, vs_src = qs, ks, vs
+        qs, ks, vs = sq.unsqueeze(0), sk.unsqueeze(0), sv.unsqueeze(0)     # step() now reads the static inputs (index 0)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step(0)
+        torch.cuda.synchronize()
+
     DS.barrier(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, i)
+        if graph is not None:
+            sq.copy_(qs_src[args.warmup + i]); sk.copy_(ks_src[args.warmup + i]); sv.copy_(vs_src[args.warmup + i])
+            graph.replay()
+        else:
+            step(args.warmup + i, i)
     DS.barrier(dev)
     elapsed = DS.max_over_ranks(time.perf_counter() - t0, dev)
+    if graph is not None:   # per-kernel durations: a short eager pass with HIP events
+        for i in range(args.steps):
+            step(0, i)
+        torch.cuda.synchronize()
 
     assert all(n == budget for n in bank.n_slots), bank.n_slots
     if rank == 0:
@@ -178,7 +198,7 @@ def main():
         t_attn = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3
         cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={L} Hq={Hq} H={H} D={D} budget={budget} "
                            f"T={T} kv_policy={args.policy} (Llama2-7B shape, budget=50% of S=4096)",
-               "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [shard.begin, shard.end], "n_split": n_split, "fused": fused,
+               "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [shard.begin, shard.end], "n_split": n_split, "fused": fused, "hipgraph": bool(args.graph),
                "handoff": (world > 1 and not args.no_handoff)}
         line = {
             "metric": "decode_tokens_per_sec", "value": world * args.steps / elapsed, "unit": "tokens/s",

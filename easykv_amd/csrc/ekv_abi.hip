@@ -121,7 +121,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   int n_split = st->n_split;
   if (n_split <= 0) {
     const int wgs = st->layer_count * bank->n_kv_heads * w.n_qblocks;
-    n_split = std::max(1, std::min((1024 + wgs - 1) / wgs, (T + 255) / 256));
+    n_split = std::max(1, std::min((1024 + wgs - 1) / wgs, st->q_len == 1 ? (T + 127) / 128 : (T + 255) / 256));
   }
   int rows = (int)ekv_align((size_t)(T + n_split - 1) / n_split, wg_unit);
   w.rows_per_split = rows;
@@ -246,10 +246,6 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.t_pad = ws.t_pad;
   aa.layer_begin = st->layer_begin;
   aa.causal = st->causal;
-  {
-    static const int stagger_env = getenv("EKV_STAGGER") ? atoi(getenv("EKV_STAGGER")) : 0;
-    aa.stagger = stagger_env;
-  }
   aa.qb_rows = ws.qb_rows;
   aa.n_qblocks = ws.n_qblocks;
   aa.sm_div = st->sm_div;
@@ -305,6 +301,8 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   if (err != hipSuccess) return EKV_E_LAUNCH;
   if (st->phases == 1) return EKV_OK;
 
+  if (ekv_decode_score_supported(sa))   // decode steps: the fast scorer (same tail as the fused kernel)
+    return ekv_launch_decode_score(sa, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   if (ekv_score_lds_bytes(sa) > 160 * 1024) return EKV_E_UNSUPPORTED;
   if (st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) {
     if (ekv_launch_tova_headmean(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;

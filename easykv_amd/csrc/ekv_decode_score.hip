@@ -1,0 +1,101 @@
+// Split-path scorer for decode steps (q_len == 1, at most one victim): one workgroup per (KV head, layer).
+// Folds the key-range-split partials of ekv_attn_decode_kernel into the fp16 output, pulls the exported logits and
+// the score rows into LDS by LDS-DMA and runs the same scorer tail as the fused kernel (ekv_decode_tail.h).
+// Used when layers are launched one at a time (heads must be split to fill the chip).
+#include "ekv_decode_tail.h"
+
+namespace {
+
+template <int REP, int ITEMS>
+__global__ void __launch_bounds__(256) ekv_decode_score_kernel(const EkvScoreArgs sc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int h = blockIdx.x, ll = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int T = sc.n_slots, D = sc.head_dim, t_pad = sc.t_pad;
+  const bool roco = sc.policy == EKV_POLICY_ROCO;
+  const bool scored = roco || sc.policy == EKV_POLICY_H2O_HEAD || sc.policy == EKV_POLICY_TOVA;
+  const int off = scored ? sc.score_off : 0;
+  const int W = T - off;
+  const int w_pad = (int)ekv_align((size_t)W, 256);
+  float* s_logit = reinterpret_cast<float*>(smem);
+  float* sS = s_logit + (size_t)REP * t_pad;
+  float* sQ = sS + w_pad;
+  float* sC = sQ + w_pad;
+  Red4 red;
+  red.buf = reinterpret_cast<unsigned long long*>(sS + (size_t)(roco ? 3 : 1) * w_pad);
+  red.phase = 0;
+  red.lane = lane;
+  red.wave = wave;
+  const size_t head_row = ((size_t)(sc.layer_begin + ll) * sc.n_kv_heads + h) * sc.cap;
+  const size_t hq0 = (size_t)ll * sc.n_q_heads + (size_t)h * REP;
+
+  if (scored) ekv_tail_prefetch_rows(sc, head_row, W, w_pad, roco, sS, sQ, sC);
+  if (scored && sc.accumulate) {   // logits rows -> LDS (rows are 256-byte aligned in the workspace)
+    const int full = t_pad / 256;
+    for (int c = wave; c < full * REP; c += 4) {
+      const int r = c / full, ch = c % full;
+      const float* src = sc.logits + (hq0 + r) * t_pad + ch * 256 + lane * 4;
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(s_logit + (size_t)r * t_pad + ch * 256), 16, 0, 0);
+    }
+    for (int r = 0; r < REP; ++r)
+      for (int j = full * 256 + tid; j < t_pad; j += 256) s_logit[(size_t)r * t_pad + j] = sc.logits[(hq0 + r) * t_pad + j];
+  }
+
+  // fold the key-range splits into the attention output
+  const int PS = D + 2;
+  for (int idx = tid; idx < REP * D; idx += 256) {
+    const int r = idx / D, d = idx % D;
+    const float* p0 = sc.partials + ((hq0 + r) * sc.n_split) * PS;
+    float mm = EKV_NEG_INF;
+    for (int s = 0; s < sc.n_split; ++s) mm = fmaxf(mm, p0[(size_t)s * PS]);
+    float ls = 0.f, os = 0.f;
+    for (int s = 0; s < sc.n_split; ++s) {
+      const float* p = p0 + (size_t)s * PS;
+      const float w = (p[0] == EKV_NEG_INF) ? 0.f : exp2f((p[0] - mm) * EKV_LOG2E);
+      ls += p[1] * w;
+      os += p[2 + d] * w;
+    }
+    sc.out[(hq0 + r) * D + d] = __float2half(os / ls);
+  }
+  __syncthreads();   // LDS-DMA complete (vmcnt(0) before the barrier) and visible
+  ekv_decode_tail<REP, ITEMS>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red);
+}
+
+size_t score_lds(int rep, int t_pad, int policy) {
+  const size_t n_state = policy == EKV_POLICY_ROCO ? 3 : 1;
+  return ((size_t)rep * t_pad + n_state * ekv_align((size_t)t_pad, 256)) * 4 + 2 * 32 * 8;
+}
+
+template <int REP, int ITEMS>
+hipError_t launch_k(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
+  const size_t lds = score_lds(REP, sc.t_pad, sc.policy);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ekv_decode_score_kernel<REP, ITEMS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((ekv_decode_score_kernel<REP, ITEMS>), dim3(sc.n_kv_heads, layer_count), dim3(256), lds, s, sc);
+  return hipGetLastError();
+}
+
+template <int REP>
+hipError_t launch_rep(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
+  return sc.n_slots <= 256 * 9 ? launch_k<REP, 9>(sc, layer_count, s) : launch_k<REP, 24>(sc, layer_count, s);
+}
+
+}  // namespace
+
+bool ekv_decode_score_supported(const EkvScoreArgs& sc) {
+  const int rep = sc.n_q_heads / sc.n_kv_heads;
+  if (sc.q_len != 1 || sc.n_evict > 1 || (sc.cap & 3) != 0 || sc.n_slots > 256 * 24) return false;
+  if (rep != 1 && rep != 2 && rep != 4 && rep != 8) return false;
+  return score_lds(rep, sc.t_pad, sc.policy) <= 150 * 1024;
+}
+
+hipError_t ekv_launch_decode_score(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
+  switch (sc.n_q_heads / sc.n_kv_heads) {
+    case 1: return launch_rep<1>(sc, layer_count, s);
+    case 2: return launch_rep<2>(sc, layer_count, s);
+    case 4: return launch_rep<4>(sc, layer_count, s);
+    case 8: return launch_rep<8>(sc, layer_count, s);
+    default: return hipErrorInvalidValue;
+  }
+}

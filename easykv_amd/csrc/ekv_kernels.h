@@ -32,7 +32,6 @@ struct EkvAttnArgs {
   const float* rope_sin;
   int32_t n_q_heads, n_kv_heads, cap, n_slots, q_len, n_split, rows_per_split, t_pad, layer_begin, causal;
   int32_t qb_rows, n_qblocks;  // chunk kernels: queries per query block, number of query blocks
-  int32_t stagger;             // fused decode: start delay (x s_sleep 64) per co-resident workgroup slot
   float sm_div;
 };
 
@@ -64,3 +63,5 @@ hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc,
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len);
 void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw);
 size_t ekv_score_lds_bytes(const EkvScoreArgs& a);
+bool ekv_decode_score_supported(const EkvScoreArgs& sc);
+hipError_t ekv_launch_decode_score(const EkvScoreArgs& sc, int layer_count, hipStream_t s);

@@ -10,8 +10,8 @@
 //   score-row compaction  easykv/easykv.py:315-333, :465-490
 // It also folds the key-range split partials of the attention kernel into the fp16 output.
 //
-// Selection is exact and deterministic: "k smallest" is a bitwise bisection on order-preserving
-// uint32 keys held in LDS (no sort, no atomics); ties go to the lowest index, NaN ranks largest.
+// Selection is exact and deterministic: "k smallest" is an MSB-first radix select (8 bits per pass) on
+// order-preserving uint32 keys held in LDS (no sort); ties go to the lowest index, NaN ranks largest.
 // The score arithmetic mirrors the reference op for op in fp32 (IEEE div/sqrt; the library is built
 // with -ffp-contract=off so q/c - (s/c)^2 is not fused).
 #include "ekv_common.h"
@@ -114,19 +114,49 @@ __device__ __forceinline__ int blk_count(Blk& b, const uint32_t* key, int n, P p
   return blk_sum_uniform(b, c);
 }
 
-// k-th smallest key (1-indexed) by bitwise bisection: 32 block-wide counts
-__device__ uint32_t blk_kth(Blk& b, const uint32_t* key, int n, int k) {
-  uint32_t tau = 0;
-  for (int bit = 31; bit >= 0; --bit) {
-    const uint32_t t = tau | (1u << bit);
-    const int c = blk_count(b, key, n, [t](uint32_t x, int) { return x < t; });
-    if (c < k) tau = t;
+// k-th smallest key (1-indexed): MSB-first radix select, 8 bits per pass (4 passes).  Per pass: a 256-bin LDS
+// histogram of the keys that still match the prefix (ds_add, worst case a few hundred cycles when every key falls in
+// one bin), then wave 0 scans the bins and publishes (bin, keys below it).  Exact; no sort.
+__device__ uint32_t blk_kth(Blk& b, const uint32_t* key, int n, int k, uint32_t* hist /* 256 + 2 words of LDS */) {
+  uint32_t prefix = 0;
+  int kk = k;   // rank still to find among the keys matching `prefix`
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = b.tid; i < 256; i += kNT) hist[i] = 0;
+    __syncthreads();
+    const uint32_t hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int j = b.tid; j < n; j += kNT) {
+      const uint32_t x = key[j];
+      if ((x & hi_mask) == prefix) atomicAdd(&hist[(x >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (b.wave == 0) {
+      const uint32_t c0 = hist[4 * b.lane], c1 = hist[4 * b.lane + 1], c2 = hist[4 * b.lane + 2], c3 = hist[4 * b.lane + 3];
+      const uint32_t mine = c0 + c1 + c2 + c3;
+      uint32_t incl = mine;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o, 64);
+        if (b.lane >= o) incl += y;
+      }
+      const uint32_t excl = incl - mine;
+      if ((uint32_t)kk > excl && (uint32_t)kk <= incl) {   // exactly one lane owns the kk-th key
+        uint32_t below = excl, bin = 4 * b.lane;
+        if ((uint32_t)kk > below + c0) { below += c0; bin++;
+          if ((uint32_t)kk > below + c1) { below += c1; bin++;
+            if ((uint32_t)kk > below + c2) { below += c2; bin++; } } }
+        hist[256] = bin;
+        hist[257] = below;
+      }
+    }
+    __syncthreads();
+    prefix |= hist[256] << shift;
+    kk -= (int)hist[257];
+    __syncthreads();
   }
-  return tau;
+  return prefix;
 }
 
 // key[j] <- 1 for the k smallest (key, index) pairs, 0 otherwise
-__device__ void blk_mark_k_smallest(Blk& b, uint32_t* key, int n, int k) {
+__device__ void blk_mark_k_smallest(Blk& b, uint32_t* key, int n, int k, uint32_t* hist) {
   uint32_t tau;
   int bound = n;
   if (k == 1) {
@@ -139,7 +169,7 @@ __device__ void blk_mark_k_smallest(Blk& b, uint32_t* key, int n, int k) {
     tau = (uint32_t)(best >> 32);
     bound = (int)(best & 0xFFFFFFFFu) + 1;
   } else {
-    tau = blk_kth(b, key, n, k);
+    tau = blk_kth(b, key, n, k, hist);
     const int n_less = blk_count(b, key, n, [tau](uint32_t x, int) { return x < tau; });
     const int n_eq = blk_count(b, key, n, [tau](uint32_t x, int) { return x == tau; });
     const int need = k - n_less;
@@ -184,6 +214,7 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
   b.wave = b.tid >> 6;
   b.red = reinterpret_cast<unsigned long long*>(smem + ekv_align((size_t)(5 * W + 2 * rows) * 4, 16));
   b.phase = 0;
+  uint32_t* sHist = reinterpret_cast<uint32_t*>(b.red) + 2 * kNWV * 8;   // 258 words
 
   const size_t head_row = ((size_t)gl * a.n_kv_heads + h) * a.cap;
   const size_t hq0 = (size_t)ll * a.n_q_heads + (size_t)h * rep;
@@ -246,17 +277,38 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
       }
       if (a.accumulate) {
         float colsum = 0.f, colsq = 0.f, last = 0.f;
-        for (int i = 0; i < n; ++i) {
-          float pb = 0.f;
-          for (int r = 0; r < rep; ++r) {
-            const int row = r * n + i;
-            const float x = a.logits[(hq0 * n + row) * a.t_pad + off + j];
-            pb += expf(x - sRowM[row]) / sRowL[row];
+        const float* col = a.logits + hq0 * n * a.t_pad + off + j;
+        if (rep == 1) {
+          // 8 independent loads in flight per thread (the rows of a column are t_pad floats apart)
+          for (int i0 = 0; i0 < n; i0 += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (i0 + u < n) ? col[(size_t)(i0 + u) * a.t_pad] : EKV_NEG_INF;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (i0 + u < n) {
+                const float pb = expf(x[u] - sRowM[i0 + u]) / sRowL[i0 + u];
+                colsum += pb;
+                colsq += pb * pb;
+                last = pb;
+              }
+            }
           }
-          if (rep > 1) pb = pb / inv_rep_div;
-          colsum += pb;
-          colsq += pb * pb;
-          last = pb;
+        } else {
+          for (int i = 0; i < n; ++i) {
+            float pb = 0.f;
+            float x[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) x[r] = (r < rep) ? col[(size_t)(r * n + i) * a.t_pad] : EKV_NEG_INF;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+              if (r < rep) pb += expf(x[r] - sRowM[r * n + i]) / sRowL[r * n + i];
+            for (int r = 8; r < rep; ++r) pb += expf(col[(size_t)(r * n + i) * a.t_pad] - sRowM[r * n + i]) / sRowL[r * n + i];
+            pb = pb / inv_rep_div;
+            colsum += pb;
+            colsq += pb * pb;
+            last = pb;
+          }
         }
         if (a.policy == EKV_POLICY_TOVA) {
           s = a.tova_head_mean ? a.tova_row[(size_t)ll * a.t_pad + off + j] : last;
@@ -325,10 +377,10 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
       }
     }
     if (victim < 0) {
-      blk_mark_k_smallest(b, sKey, W, a.roco_k1);  // feasible set
+      blk_mark_k_smallest(b, sKey, W, a.roco_k1, sHist);  // feasible set
       for (int j = b.tid; j < W; j += kNT) sKey[j] = sKey[j] ? sKey2[j] : 0xFFFFFFFFu;
       __syncthreads();
-      blk_mark_k_smallest(b, sKey, W, k);
+      blk_mark_k_smallest(b, sKey, W, k, sHist);
     }
   } else {  // h2o_head / tova: k smallest accumulated scores inside the candidate window
     if (k == 1) {
@@ -342,7 +394,7 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
       for (int j = b.tid; j < W; j += kNT)
         sKey[j] = (j >= a.win_lo && j < W - a.win_tail) ? ekv_fkey(sS[j]) : 0xFFFFFFFFu;
       __syncthreads();
-      blk_mark_k_smallest(b, sKey, W, k);
+      blk_mark_k_smallest(b, sKey, W, k, sHist);
     }
   }
   const bool roco = a.policy == EKV_POLICY_ROCO;
@@ -484,7 +536,7 @@ size_t ekv_score_lds_bytes(const EkvScoreArgs& a) {
   const bool scored = a.policy == EKV_POLICY_H2O_HEAD || a.policy == EKV_POLICY_ROCO || a.policy == EKV_POLICY_TOVA;
   const int W = a.n_slots - (scored ? a.score_off : 0);
   const int rows = (a.n_q_heads / a.n_kv_heads) * a.q_len;
-  return ekv_align((size_t)(5 * W + 2 * rows) * 4, 16) + 2 * kNWV * 8 * 4;
+  return ekv_align((size_t)(5 * W + 2 * rows) * 4, 16) + 2 * kNWV * 8 * 4 + 260 * 4;
 }
 
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s) {
