@@ -1,0 +1,87 @@
+"""API behaviours of the host mirror that the reference's users rely on (SURVEY.md §8 'quirks'), on the GPU."""
+import contextlib
+import io
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(length=120, L=2, Hq=4, H=4, D=32, seed=5):
+    from oracle.fake_model import make_streams
+    from tests.native_fake_model import NativeFakeModel
+    return NativeFakeModel(*make_streams(L, Hq, H, D, length + 64, seed))
+
+
+def _run(model, mode, stride, length, **cfg):
+    import easykv_amd
+    ids = torch.arange(length).view(1, -1) % 16
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res, cache = easykv_amd.generate(model, ids, dict(cfg, eos_token_ids=[-1]), kv_mode=mode, stride=stride, return_cache=True)
+    return res, cache, buf.getvalue().strip()
+
+
+def test_full_budget_takes_the_plain_prefill_branch():
+    # easykv/easykv.py:372-377: float budget >= 1.0 or int budget >= length -> no eviction at all
+    for budget in (1.0, 500):
+        res, cache, line = _run(_model(), "encoding", 8, 120, budget=budget, kv_policy="roco", max_new_tokens=3)
+        assert line == "KV cache budget ratio: 100.00%(120/120)"
+        assert cache.get_seq_length() == 123
+
+
+def test_auto_mode_asserts_like_the_reference():
+    with pytest.raises(AssertionError):     # stride 1 (easykv/easykv.py:666-669)
+        _run(_model(), "auto", 1, 120, budget=40, kv_policy="roco", max_new_tokens=2)
+    with pytest.raises(AssertionError):     # h2o_head is not white-listed (:536-537)
+        _run(_model(), "auto", 4, 120, budget=40, kv_policy="h2o_head", max_new_tokens=2)
+    with pytest.raises(AssertionError):     # float budget (:222)
+        _run(_model(), "auto", 4, 120, budget=0.5, kv_policy="roco", max_new_tokens=2)
+    with pytest.raises(UnboundLocalError):  # random is broken in auto mode (:744)
+        _run(_model(), "auto", 4, 120, budget=40, kv_policy="random", max_new_tokens=2, recent_ratio=0.3)
+
+
+@pytest.mark.parametrize("mode,stride", [("decoding", 1), ("encoding", 4)])
+def test_random_policy_keeps_the_budget(mode, stride):
+    torch.manual_seed(0)
+    length = 16 if mode == "decoding" else 100
+    cfg = dict(budget=24 if mode == "decoding" else 0.5, kv_policy="random", max_new_tokens=40 if mode == "decoding" else 3)
+    res, cache, line = _run(_model(length), mode, stride, length, **cfg)
+    if mode == "decoding":
+        assert line == "KV cache budget ratio: 60.00%(24/40)"
+    else:
+        assert line == "KV cache budget ratio: 52.00%(52/100)"
+
+
+def test_ppl_int_budget_is_full_like_the_reference():
+    # easykv/easykv.py:759: `if budget >= 1.0` catches every int budget (SURVEY.md probe 9)
+    a, _, _ = _run(_model(64), "ppl", 4, 64, budget=40, kv_policy="roco")
+    b, _, _ = _run(_model(64), "ppl", 4, 64, budget=1.0, kv_policy="roco")
+    assert a == b
+
+
+def test_layers_can_be_launched_one_by_one_or_batched():
+    """The same step through per-layer launches (split path) and one batched launch (fused path) evicts the same slots."""
+    from easykv_amd import KVBank, StepPlan
+    L, Hq, H, D, T0, budget = 4, 8, 8, 128, 300, 299
+    g = torch.Generator().manual_seed(11)
+    k0, v0 = torch.randn(L, H, T0, D, generator=g).half().cuda(), torch.randn(L, H, T0, D, generator=g).half().cuda()
+    banks = [KVBank(L, Hq, H, D, cap=T0 + 8) for _ in range(2)]
+    for b in banks:
+        b.load_rows(k0, v0)
+        b.state_init(budget + 1, 0)
+    for step in range(12):
+        q, k, v = (torch.randn(L, h, 1, D, generator=g).half().cuda() for h in (Hq, H, H))
+        plan = StepPlan(policy="roco", phase="decode", evict=True, budget=budget)
+        plan_b = StepPlan(policy="roco", phase="decode", evict=True, budget=budget, n_split=1)   # one workgroup per head: fused
+        o_b, ids_b = banks[0].attend(plan_b, q, k, v)
+        outs, ids = [], []
+        for l in range(L):
+            o, i = banks[1].attend(plan, q[l:l + 1], k[l:l + 1], v[l:l + 1], layer_begin=l)
+            outs.append(o)
+            ids.append(i)
+        assert torch.equal(ids_b, torch.cat(ids))
+        assert torch.allclose(o_b.float(), torch.cat(outs).float(), atol=2e-3, rtol=1e-3)
+    assert banks[0].step_plan(plan_b, 1)[1] is True        # batched, unsplit: one fused launch
+    assert banks[1].step_plan(plan, 1, 0, 1)[1] is False   # single layer: split path
