@@ -168,7 +168,7 @@ int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, in
   if (!st || !n_split || !fused) return EKV_E_ARG;
   const EkvWs ws = ekv_plan_workspace(bank, st, nullptr);
   *n_split = ws.n_split;
-  *fused = (st->q_len == 1 && st->phases == 0 && ws.n_split == 1 &&
+  *fused = (st->q_len == 1 && st->phases == 0 && st->n_split != -1 && ws.n_split == 1 &&
             ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, st->n_evict, bank->cap))
                ? 1 : 0;
   return EKV_OK;
@@ -289,8 +289,13 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
     return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
 
+  // phases: 0 = whole step; else a bit mask: 1 attention kernel, 2 scorer (fold + score), 4 fold only, 8 scorer
+  // without the fold (4 and 8 let the caller run the scorer on a side stream, off the critical path)
+  const int ph = st->phases;
+  if (ph < 0 || ph > 15 || ((ph & 2) && (ph & (4 | 8)))) return EKV_E_ARG;
+  if ((ph & (4 | 8)) && n != 1) return EKV_E_UNSUPPORTED;
   hipError_t err = hipSuccess;
-  if (st->phases == 2) {
+  if (ph != 0 && !(ph & 1)) {
   } else if (n == 1) {
     if (!ekv_attn_decode_supported(bank->head_dim, rep)) return EKV_E_UNSUPPORTED;
     err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
@@ -299,8 +304,17 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
     err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, s);
   }
   if (err != hipSuccess) return EKV_E_LAUNCH;
-  if (st->phases == 1) return EKV_OK;
+  if (ph == 1) return EKV_OK;
 
+  if (ph & 4) {
+    if (ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+    if (!(ph & 8)) return EKV_OK;
+  }
+  sa.skip_fold = (ph & 8) ? 1 : 0;
+  if (ph & 8) {
+    if (!ekv_decode_score_supported(sa)) return EKV_E_UNSUPPORTED;
+    return ekv_launch_decode_score(sa, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+  }
   if (ekv_decode_score_supported(sa))   // decode steps: the fast scorer (same tail as the fused kernel)
     return ekv_launch_decode_score(sa, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   if (ekv_score_lds_bytes(sa) > 160 * 1024) return EKV_E_UNSUPPORTED;

@@ -69,4 +69,35 @@ __device__ __forceinline__ uint32_t ekv_fkey(float x) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// Fold the key-range-split partials (m, l, o[D]) of one query row into o[d] / l.  All loads of a pass are issued
+// together (up to 32 splits per batch): a naive loop serialises one L2 round trip per split (~10 us for 17 splits).
+__device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split, int PS, int d) {
+  float mm = EKV_NEG_INF, ls = 0.f, os = 0.f;
+  for (int s0 = 0; s0 < n_split; s0 += 32) {
+    float mv[32], lv[32], ov[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const bool ok = s0 + i < n_split;
+      const float* p = p0 + (size_t)(ok ? s0 + i : 0) * PS;
+      mv[i] = ok ? p[0] : EKV_NEG_INF;
+      lv[i] = ok ? p[1] : 0.f;
+      ov[i] = ok ? p[2 + d] : 0.f;
+    }
+    float mb = mm;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) mb = fmaxf(mb, mv[i]);
+    const float rescale = (mm == EKV_NEG_INF) ? 0.f : exp2f((mm - mb) * EKV_LOG2E);
+    ls *= rescale;
+    os *= rescale;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float w = (mv[i] == EKV_NEG_INF) ? 0.f : exp2f((mv[i] - mb) * EKV_LOG2E);
+      ls += lv[i] * w;
+      os += ov[i] * w;
+    }
+    mm = mb;
+  }
+  return os / ls;
+}
+
 static inline __host__ __device__ size_t ekv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }

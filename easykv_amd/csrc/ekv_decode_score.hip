@@ -43,22 +43,20 @@ __global__ void __launch_bounds__(256) ekv_decode_score_kernel(const EkvScoreArg
 
   // fold the key-range splits into the attention output
   const int PS = D + 2;
-  for (int idx = tid; idx < REP * D; idx += 256) {
+  for (int idx = tid; idx < (sc.skip_fold ? 0 : REP * D); idx += 256) {
     const int r = idx / D, d = idx % D;
-    const float* p0 = sc.partials + ((hq0 + r) * sc.n_split) * PS;
-    float mm = EKV_NEG_INF;
-    for (int s = 0; s < sc.n_split; ++s) mm = fmaxf(mm, p0[(size_t)s * PS]);
-    float ls = 0.f, os = 0.f;
-    for (int s = 0; s < sc.n_split; ++s) {
-      const float* p = p0 + (size_t)s * PS;
-      const float w = (p[0] == EKV_NEG_INF) ? 0.f : exp2f((p[0] - mm) * EKV_LOG2E);
-      ls += p[1] * w;
-      os += p[2 + d] * w;
-    }
-    sc.out[(hq0 + r) * D + d] = __float2half(os / ls);
+    sc.out[(hq0 + r) * D + d] = __float2half(ekv_fold_partials(sc.partials + ((hq0 + r) * sc.n_split) * PS, sc.n_split, PS, d));
   }
   __syncthreads();   // LDS-DMA complete (vmcnt(0) before the barrier) and visible
   ekv_decode_tail<REP, ITEMS>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red);
+}
+
+// Partials of the key-range splits -> fp16 attention output, nothing else (rows = q_len * n_q_heads per layer).
+__global__ void __launch_bounds__(128) ekv_fold_kernel(const EkvScoreArgs sc) {
+  const int D = sc.head_dim, PS = D + 2;
+  const size_t row = (size_t)blockIdx.y * sc.n_q_heads * sc.q_len + blockIdx.x;
+  const float* p0 = sc.partials + row * sc.n_split * PS;
+  for (int d = threadIdx.x; d < D; d += 128) sc.out[row * D + d] = __float2half(ekv_fold_partials(p0, sc.n_split, PS, d));
 }
 
 size_t score_lds(int rep, int t_pad, int policy) {
@@ -88,6 +86,11 @@ bool ekv_decode_score_supported(const EkvScoreArgs& sc) {
   if (sc.q_len != 1 || sc.n_evict > 1 || (sc.cap & 3) != 0 || sc.n_slots > 256 * 24) return false;
   if (rep != 1 && rep != 2 && rep != 4 && rep != 8) return false;
   return score_lds(rep, sc.t_pad, sc.policy) <= 150 * 1024;
+}
+
+hipError_t ekv_launch_fold(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
+  hipLaunchKernelGGL(ekv_fold_kernel, dim3(sc.n_q_heads * sc.q_len, layer_count), dim3(128), 0, s, sc);
+  return hipGetLastError();
 }
 
 hipError_t ekv_launch_decode_score(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {

@@ -49,6 +49,7 @@ struct EkvScoreArgs {
   int32_t score_off, policy, accumulate, n_evict, win_lo, win_tail, roco_k1, roco_tail, range_start, tova_head_mean,
       causal;
   float count_add, count_tail_step;
+  int32_t skip_fold;   // 1: the attention output was already folded by ekv_fold_kernel (scorer off the critical path)
 };
 
 EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* step, void* base);
@@ -65,3 +66,4 @@ void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw
 size_t ekv_score_lds_bytes(const EkvScoreArgs& a);
 bool ekv_decode_score_supported(const EkvScoreArgs& sc);
 hipError_t ekv_launch_decode_score(const EkvScoreArgs& sc, int layer_count, hipStream_t s);
+hipError_t ekv_launch_fold(const EkvScoreArgs& sc, int layer_count, hipStream_t s);

@@ -223,17 +223,7 @@ __global__ void __launch_bounds__(kNT) ekv_score_select_kernel(const EkvScoreArg
   const int PS = D + 2;
   for (int idx = b.tid; idx < rows * D; idx += kNT) {
     const int row = idx / D, d = idx % D;  // row = r*n + i
-    const float* p0 = a.partials + ((hq0 * n + row) * a.n_split) * PS;
-    float mm = EKV_NEG_INF;
-    for (int s = 0; s < a.n_split; ++s) mm = fmaxf(mm, p0[(size_t)s * PS]);
-    float ls = 0.f, os = 0.f;
-    for (int s = 0; s < a.n_split; ++s) {
-      const float* p = p0 + (size_t)s * PS;
-      const float w = (p[0] == EKV_NEG_INF) ? 0.f : exp2f((p[0] - mm) * EKV_LOG2E);
-      ls += p[1] * w;
-      os += p[2 + d] * w;
-    }
-    a.out[(hq0 * n + row) * D + d] = __float2half(os / ls);
+    a.out[(hq0 * n + row) * D + d] = __float2half(ekv_fold_partials(a.partials + ((hq0 * n + row) * a.n_split) * PS, a.n_split, PS, d));
   }
 
   if (scored) {

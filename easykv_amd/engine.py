@@ -61,6 +61,13 @@ class KVBank:
         self.score_cnt = torch.zeros_like(self.score_sum) if scored else None
         self.n_slots = [0] * n_layers
         self._ws = None
+        # scorer off the critical path (attend(..., overlap_scorer=True)): side streams, a ring of workspaces and, per
+        # layer, the event after which its slot map / score rows are up to date again
+        self._side = None
+        self._ws_ring = []
+        self._ws_free = []
+        self._ring_pos = 0
+        self._score_done = [None] * n_layers
         self._bank = Bank(self.k.data_ptr(), self.v.data_ptr(), self.slot_of_pos.data_ptr(),
                           self.score_sum.data_ptr() if scored else None, self.score_sq.data_ptr() if scored else None,
                           self.score_cnt.data_ptr() if scored else None, n_layers, n_q_heads, n_kv_heads, head_dim, cap)
@@ -158,7 +165,48 @@ class KVBank:
         check(self.lib.ekv_step_plan(C.byref(self._bank), C.byref(st), C.byref(ns), C.byref(fu)), "ekv_step_plan")
         return ns.value, bool(fu.value)
 
-    def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None, phases=0):
+    def join(self):
+        """Make the current stream wait for every scorer still running on a side stream."""
+        cur = torch.cuda.current_stream(self.device)
+        for l, ev in enumerate(self._score_done):
+            if ev is not None:
+                cur.wait_event(ev)
+                self._score_done[l] = None
+        self._ws_free = [None] * len(self._ws_free)     # every scorer joined: all workspace slots are free again
+
+    def _attend_overlapped(self, st, q, k_new, v_new, out, evict_ids, lc, layer_begin):
+        """Attention + fold on the current stream (the attention output is ready as early as possible); the scorer
+        (accumulate / select / compaction) on a side stream.  The next attention of these layers waits for it."""
+        if self._side is None:
+            self._side = [torch.cuda.Stream(self.device) for _ in range(4)]
+        main = torch.cuda.current_stream(self.device)
+        need = self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st))
+        if not self._ws_ring or self._ws_ring[0].numel() < need:
+            self._ws_ring = [torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.device) for _ in range(8)]
+            self._ws_free = [None] * 8
+        slot = self._ring_pos
+        self._ring_pos = (slot + 1) % len(self._ws_ring)
+        ws = self._ws_ring[slot]
+        for ev in [self._ws_free[slot]] + self._score_done[layer_begin:layer_begin + lc]:
+            if ev is not None:
+                main.wait_event(ev)      # workspace slot free again; slot map / score rows of these layers up to date
+        args = (_ptr(q), _ptr(k_new), _ptr(v_new), _ptr(out), _ptr(evict_ids) if st.n_evict > 0 else None,
+                _ptr(self.rope_cos), _ptr(self.rope_sin), _ptr(ws), ws.numel())
+        st.phases = 1 | 4
+        check(self.lib.ekv_step_attend(C.byref(self._bank), C.byref(st), *args, C.c_void_p(main.cuda_stream)), "ekv_step_attend")
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side = self._side[slot % len(self._side)]
+        side.wait_event(ready)
+        st.phases = 8
+        check(self.lib.ekv_step_attend(C.byref(self._bank), C.byref(st), *args, C.c_void_p(side.cuda_stream)), "ekv_step_attend")
+        done = torch.cuda.Event()
+        done.record(side)
+        self._ws_free[slot] = done
+        for l in range(layer_begin, layer_begin + lc):
+            self._score_done[l] = done
+
+    def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None, phases=0, overlap_scorer=False):
         """q ``[layers, Hq, n, D]``, k_new/v_new ``[layers, H, n, D]`` (fp16, device).
         Returns (out ``[layers, Hq, n, D]`` fp16, evict_ids ``[layers, H, k]`` int32 or None)."""
         lc, _, n, _ = q.shape
@@ -168,6 +216,13 @@ class KVBank:
             out = torch.empty(lc, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
         if st.n_evict > 0 and evict_ids is None:
             evict_ids = torch.empty(lc, self.n_kv_heads, st.n_evict, dtype=torch.int32, device=self.device)
+        if overlap_scorer and phases == 0 and n == 1 and not self.step_plan(plan, n, layer_begin, lc)[1]:
+            self._attend_overlapped(st, q, k_new, v_new, out, evict_ids, lc, layer_begin)
+            for l in range(layer_begin, layer_begin + lc):
+                self.n_slots[l] = st.n_slots - st.n_evict
+            return out, (evict_ids if st.n_evict > 0 else None)
+        if any(ev is not None for ev in self._score_done[layer_begin:layer_begin + lc]):
+            self.join()
         need = self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st))
         ws = self._workspace(need)
         check(self.lib.ekv_step_attend(C.byref(self._bank), C.byref(st), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(out),

@@ -88,7 +88,8 @@ typedef struct ekv_step {
   int32_t causal;       /* 1: the last q_len positions are the chunk itself, causal inside it            */
   int32_t rope_on_read; /* 1: streaming variant, rotate keys by position index at read time             */
   int32_t n_split;      /* key-range splits per head (0 = choose)                                        */
-  int32_t phases;       /* 0 = whole step; 1 = attention kernel only; 2 = score/select kernel only (profiling) */
+  int32_t phases;       /* 0 = whole step; else bit mask: 1 attention kernel, 2 scorer (fold+score), 4 fold only, 8 scorer
+                           without the fold (1|4 then 8 lets the caller run the scorer on a side stream)          */
   float count_add;      /* added to C before selection (1 decode, stride prefill); 0 = leave             */
   float count_tail_step;/* C tail after compaction: tail[i] = i * count_tail_step (0 decode, -1 prefill) */
   float sm_div;         /* logits are divided by this (sqrt(head_dim))                                   */

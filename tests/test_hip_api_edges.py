@@ -85,3 +85,27 @@ def test_layers_can_be_launched_one_by_one_or_batched():
         assert torch.allclose(o_b.float(), torch.cat(outs).float(), atol=2e-3, rtol=1e-3)
     assert banks[0].step_plan(plan_b, 1)[1] is True        # batched, unsplit: one fused launch
     assert banks[1].step_plan(plan, 1, 0, 1)[1] is False   # single layer: split path
+
+
+def test_overlapped_scorer_matches_inline_scorer():
+    """Scorer on a side stream (attention + fold first, score/select/compaction asynchronously) == inline scorer."""
+    from easykv_amd import KVBank, StepPlan
+    L, Hq, H, D, T0, budget = 3, 8, 8, 128, 300, 299
+    g = torch.Generator().manual_seed(12)
+    k0, v0 = torch.randn(L, H, T0, D, generator=g).half().cuda(), torch.randn(L, H, T0, D, generator=g).half().cuda()
+    banks = [KVBank(L, Hq, H, D, cap=T0 + 8) for _ in range(2)]
+    for b in banks:
+        b.load_rows(k0, v0)
+        b.state_init(budget + 1, 0)
+    for step in range(20):
+        q, k, v = (torch.randn(L, h, 1, D, generator=g).half().cuda() for h in (Hq, H, H))
+        plan = StepPlan(policy="roco", phase="decode", evict=True, budget=budget)
+        for l in range(L):
+            o0, i0 = banks[0].attend(plan, q[l:l + 1], k[l:l + 1], v[l:l + 1], layer_begin=l)
+            o1, i1 = banks[1].attend(plan, q[l:l + 1], k[l:l + 1], v[l:l + 1], layer_begin=l, overlap_scorer=True)
+            torch.cuda.synchronize()
+            assert torch.equal(i0, i1) and torch.equal(o0, o1)
+    banks[1].join()
+    torch.cuda.synchronize()
+    assert torch.equal(banks[0].slot_of_pos, banks[1].slot_of_pos)
+    assert torch.equal(banks[0].score_sum, banks[1].score_sum)
