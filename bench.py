@@ -196,6 +196,18 @@ def main():
     bank.join()
     torch.cuda.synchronize()
     assert all(n == budget for n in bank.n_slots), bank.n_slots
+
+    # secondary figure (not `value`): the same step issued one layer per launch, as a real sequential model does
+    seq = None
+    if rank == 0 and lpl == L and not args.graph and L > 1:
+        n_seq = max(4, min(16, args.steps))
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(n_seq):
+            for l0 in range(L):
+                bank.attend(plan, qs[i, l0:l0 + 1], ks[i, l0:l0 + 1], vs[i, l0:l0 + 1], layer_begin=l0, out=out[l0:l0 + 1], evict_ids=ids[l0:l0 + 1])
+        torch.cuda.synchronize()
+        seq = n_seq / (time.perf_counter() - ts)
     if rank == 0:
         n_state = {"roco": 3, "h2o_head": 1, "tova": 1}.get(args.policy, 0)
         b = algorithmic_bytes(H, Hq, D, T, 1, n_state)
@@ -210,10 +222,23 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 accumulate",
             "data": "synthetic", "config": cfg}
+        if seq is not None:
+            line["per_layer_launches"] = {"value": seq, "unit": "tokens/s", "note": "same step, one layer per launch (split path: "
+                                          "attention kernel + scorer kernel per layer), latency-bound; not the headline value"}
+        traffic, traffic_src = None, None
+        summ = os.path.join(ROOT, "profiles", "r01_decode_summary.json")
+        if fused and os.path.exists(summ) and (L, Hq, H, D, budget, args.policy, lpl) == (32, 32, 32, 128, 2048, "roco", 32):
+            try:
+                pm = json.load(open(summ)).get("pmc", {})
+                k = [v for n, v in pm.items() if "ekv_decode_fused_kernel<128, 1, false" in n]
+                if k and "hbm_bytes_per_launch" in k[0]:
+                    traffic, traffic_src = k[0]["hbm_bytes_per_launch"], "profiles/r01_decode_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE (gfx950 correction), same command"
+            except Exception:
+                pass
         if fused:
             gbs = b["total"] * lc0 / t_attn / 1e9
             line["roofline"] = {"bound": "hbm", "kernel": "ekv_decode_fused_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                 "bytes_per_launch": b["total"] * lc0, "avg_launch_us": t_attn * 1e6}
         elif args.overlap_scorer:
             line["roofline"] = None     # kernels of different layers overlap: per-kernel event timing is not meaningful here
