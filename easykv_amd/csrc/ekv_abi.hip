@@ -121,7 +121,10 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   int n_split = st->n_split;
   if (n_split <= 0) {
     const int wgs = st->layer_count * bank->n_kv_heads * w.n_qblocks;
-    n_split = std::max(1, std::min((1024 + wgs - 1) / wgs, st->q_len == 1 ? (T + 127) / 128 : (T + 255) / 256));
+    // decode: >= 1024 workgroups (4 per CU, one round).  chunk kernels hold 3 (QPW=1) or 2 workgroups per CU: a grid of
+    // exactly 1024 would leave a quarter of it to a second, nearly empty round, so QPW=1 aims at 4 full rounds (3072).
+    const int target = (st->q_len > 1 && qpw == 1) ? 3072 : 1024;
+    n_split = std::max(1, std::min((target + wgs - 1) / wgs, st->q_len == 1 ? (T + 127) / 128 : (T + 255) / 256));
   }
   int rows = (int)ekv_align((size_t)(T + n_split - 1) / n_split, wg_unit);
   w.rows_per_split = rows;

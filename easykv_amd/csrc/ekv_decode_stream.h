@@ -26,13 +26,14 @@ struct EkvDecodeGeom {
 // one iteration ahead.  Logits (q.k / sm_div) go to `logit_out` (+ `logit_stride` per query head): workspace or LDS.
 template <int D, int REP, bool ROPE, bool SLOT_LDS>
 __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
-                                                  int logit_stride, int t0, int t1, int ll, int h, size_t head_row,
+                                                  int logit_stride, int t0, int t1_in, int ll, int h, size_t head_row,
                                                   float (&m)[REP], float (&l)[REP], float (&o)[REP][8]) {
   using Gm = EkvDecodeGeom<D>;
   constexpr int LPR = Gm::LPR, RW = Gm::RW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int t_new = a.n_slots - 1;  // the appended position
+  int t1 = t1_in;
 
   uint4 qv[REP];
   float qf[REP][8], qr[REP][8];  // ROPE: rotated query and its rotate_half partner, fp32
@@ -78,6 +79,38 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     for (int i = 0; i < 8; ++i) o[r][i] = 0.f;
   }
 
+  // The appended row is peeled off the loop: its K/V come from k_new/v_new, one lane group scores it here, and the loop
+  // covers [t0, t_new) — with T = budget + 1 = 2049 that is exactly 16 full iterations instead of 17.
+  const bool has_new = t_new >= t0 && t_new < t1;
+  if (has_new) t1 = t_new;
+  if (has_new && wave == 0 && grp == 0) {
+    const uint4 kn = reinterpret_cast<const uint4*>(k_new_row)[sub];
+    const uint4 vn = reinterpret_cast<const uint4*>(v_new_row)[sub];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) {
+      float acc;
+      if (ROPE) {
+        const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)t_new * D + sub * 8);
+        const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)t_new * D + sub * 8);
+        const float4 c0 = c4[0], c1 = c4[1], s0 = s4[0], s1 = s4[1];
+        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const ekv_h8 kh = __builtin_bit_cast(ekv_h8, kn);
+        acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = fmaf((float)kh[i], fmaf(qr[r][i], ss[i], qf[r][i] * cc[i]), acc);
+      } else {
+        acc = ekv_dot8(qv[r], kn, 0.f);
+      }
+      acc = ekv_group_sum<LPR>(acc) / a.sm_div;
+      if (logit_out != nullptr && sub == 0) logit_out[(size_t)r * logit_stride + t_new] = acc;
+      m[r] = acc;      // p = exp(acc - m) = 1
+      l[r] = 1.f;
+      ekv_axpy8(1.f, vn, o[r]);
+    }
+  }
+  if (t1 <= t0) return;   // the split held only the appended row
+
   static_assert(kU == 8, "index prefetch assumes 8 rows per lane group");
   const int last_slot = s_slot[t1 - 1 - slot_base];
   const int idx_cap = (a.cap - 8) & ~7;   // prefetches past t1 stay inside the head's map row (values unused)
@@ -101,10 +134,8 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
       const int j = j0 + u;
       const int jj = j < t1 ? j : t1 - 1;
       const int row = SLOT_LDS ? s_slot[jj - t0] : (j < t1 ? cur[u] : last_slot);
-      // the appended position is read from k_new/v_new (pointer select, no branch in the hot loop)
-      const bool is_new = jj == t_new;
-      const __half* kp = is_new ? k_new_row : a.k + (head_row + row) * D;
-      const __half* vp = is_new ? v_new_row : a.v + (head_row + row) * D;
+      const __half* kp = a.k + (head_row + row) * D;
+      const __half* vp = a.v + (head_row + row) * D;
       // K/V rows are read exactly once per step and the cache (>1 GB) never fits L2/MALL: non-temporal loads
       // (measured on MI355X: 5.5 -> 6.1 TB/s on the pure stream)
       kr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(kp) + sub));

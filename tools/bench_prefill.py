@@ -1,0 +1,34 @@
+import sys, time, torch
+sys.path.insert(0,'.')
+from easykv_amd import KVBank, StepPlan, geometry
+L,Hq,H,D = 32,32,int(sys.argv[2]) if len(sys.argv)>2 else 32,128
+S, stride, budget = 4096, int(sys.argv[1]) if len(sys.argv)>1 else 8, 0.5
+NSPLIT = int(sys.argv[3]) if len(sys.argv)>3 else 0
+bp, idx, r_idx = geometry("encoding", S, budget, stride)
+recent, sink = int(bp*0.1), 4
+dev=torch.device('cuda'); g=torch.Generator(device=dev).manual_seed(0)
+bank=KVBank(L,Hq,H,D,cap=idx+stride)
+def rnd(h,n): return torch.randn(L,h,n,D,generator=g,device=dev).half()
+# dense prefix, layer blocks of 8 to bound the workspace
+torch.cuda.synchronize(); t0=time.perf_counter()
+for l0 in range(0,L,8):
+    q,k,v = (x[l0:l0+8].contiguous() for x in (rnd(Hq,r_idx),rnd(H,r_idx),rnd(H,r_idx)))
+    bank.attend(StepPlan(policy='full',phase='prefill',accumulate=False), q,k,v, layer_begin=l0)
+torch.cuda.synchronize(); t_prefix=time.perf_counter()-t0
+bank.state_init(idx+stride,2,stride)
+n_chunks=(S-r_idx)//stride
+qs=[rnd(Hq,stride) for _ in range(4)]; ks=[rnd(H,stride) for _ in range(4)]; vs=[rnd(H,stride) for _ in range(4)]
+ev=[]
+torch.cuda.synchronize(); t0=time.perf_counter()
+for c in range(n_chunks):
+    t_now=bank.n_slots[0]+stride
+    plan=StepPlan(policy='roco',phase='prefill',accumulate=t_now>idx,evict=t_now>idx,budget=bp,recent=recent,sink=sink,stride=stride,tova_head_mean=True,n_split=NSPLIT)
+    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e2=torch.cuda.Event(enable_timing=True)
+    e0.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4],phases=1); e1.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4],phases=2); e2.record()
+    ev.append((e0,e1,e2))
+torch.cuda.synchronize(); t_chunks=time.perf_counter()-t0
+ta=sum(a.elapsed_time(b) for a,b,_ in ev[2:])/len(ev[2:])*1e3; ts=sum(b.elapsed_time(c) for _,b,c in ev[2:])/len(ev[2:])*1e3
+T=idx+stride
+bytes_attn = L*(2*H*T*D*2 + 2*Hq*stride*D*2 + 2*H*stride*D*2)
+print(f"stride {stride} H {H} n_split {NSPLIT}: geometry bp={bp} idx={idx} r_idx={r_idx} T={T}; dense prefix {r_idx} tok x {L} layers: {t_prefix*1e3:.1f} ms")
+print(f"chunk step (32 layers/launch): attn {ta:.1f} us ({bytes_attn/ta/1e3:.0f} GB/s alg) + score/select {ts:.1f} us ; {n_chunks} chunks in {t_chunks*1e3:.1f} ms -> {stride*n_chunks/t_chunks:.0f} prefill tok/s (chunk phase)")
