@@ -70,13 +70,14 @@ __device__ __forceinline__ uint32_t ekv_fkey(float x) {
 }
 
 // Fold the key-range-split partials (m, l, o[D]) of one query row into o[d] / l.  All loads of a pass are issued
-// together (up to 32 splits per batch): a naive loop serialises one L2 round trip per split (~10 us for 17 splits).
+// together (BATCH splits per round trip): a naive loop serialises one L2 round trip per split (~10 us for 17 splits).
+template <int BATCH = 32>
 __device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split, int PS, int d) {
   float mm = EKV_NEG_INF, ls = 0.f, os = 0.f;
-  for (int s0 = 0; s0 < n_split; s0 += 32) {
-    float mv[32], lv[32], ov[32];
+  for (int s0 = 0; s0 < n_split; s0 += BATCH) {
+    float mv[BATCH], lv[BATCH], ov[BATCH];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < BATCH; ++i) {
       const bool ok = s0 + i < n_split;
       const float* p = p0 + (size_t)(ok ? s0 + i : 0) * PS;
       mv[i] = ok ? p[0] : EKV_NEG_INF;
@@ -85,12 +86,12 @@ __device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split,
     }
     float mb = mm;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) mb = fmaxf(mb, mv[i]);
+    for (int i = 0; i < BATCH; ++i) mb = fmaxf(mb, mv[i]);
     const float rescale = (mm == EKV_NEG_INF) ? 0.f : exp2f((mm - mb) * EKV_LOG2E);
     ls *= rescale;
     os *= rescale;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < BATCH; ++i) {
       const float w = (mv[i] == EKV_NEG_INF) ? 0.f : exp2f((mv[i] - mb) * EKV_LOG2E);
       ls += lv[i] * w;
       os += ov[i] * w;

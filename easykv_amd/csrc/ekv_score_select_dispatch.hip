@@ -1,0 +1,21 @@
+// Block-size dispatch of the generic scorer: 256-thread workgroups when the grid alone fills the chip (more workgroups
+// resident per CU, cheaper barriers), 512 threads when there are few (head, layer) pairs.
+#include "ekv_common.h"
+#include "ekv_kernels.h"
+
+size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs&);
+size_t ekv_score_lds_bytes_nt512(const EkvScoreArgs&);
+hipError_t ekv_launch_score_select_nt256(const EkvScoreArgs&, int, hipStream_t);
+hipError_t ekv_launch_score_select_nt512(const EkvScoreArgs&, int, hipStream_t);
+hipError_t ekv_launch_tova_headmean_nt512(const EkvScoreArgs&, int, hipStream_t);
+
+size_t ekv_score_lds_bytes(const EkvScoreArgs& a) { return ekv_score_lds_bytes_nt512(a); }
+
+hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s) {
+  return (a.n_kv_heads * layer_count >= 768) ? ekv_launch_score_select_nt256(a, layer_count, s)
+                                             : ekv_launch_score_select_nt512(a, layer_count, s);
+}
+
+hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s) {
+  return ekv_launch_tova_headmean_nt512(a, layer_count, s);
+}

@@ -4,6 +4,8 @@ from easykv_amd import KVBank, StepPlan, geometry
 L,Hq,H,D = 32,32,int(sys.argv[2]) if len(sys.argv)>2 else 32,128
 S, stride, budget = 4096, int(sys.argv[1]) if len(sys.argv)>1 else 8, 0.5
 NSPLIT = int(sys.argv[3]) if len(sys.argv)>3 else 0
+import os
+POLICY = os.environ.get('POLICY','roco'); NOEVICT = os.environ.get('NOEVICT','0')=='1'
 bp, idx, r_idx = geometry("encoding", S, budget, stride)
 recent, sink = int(bp*0.1), 4
 dev=torch.device('cuda'); g=torch.Generator(device=dev).manual_seed(0)
@@ -22,7 +24,8 @@ ev=[]
 torch.cuda.synchronize(); t0=time.perf_counter()
 for c in range(n_chunks):
     t_now=bank.n_slots[0]+stride
-    plan=StepPlan(policy='roco',phase='prefill',accumulate=t_now>idx,evict=t_now>idx,budget=bp,recent=recent,sink=sink,stride=stride,tova_head_mean=True,n_split=NSPLIT)
+    if NOEVICT and t_now+stride>bank.cap: break
+    plan=StepPlan(policy=POLICY,phase='prefill',accumulate=t_now>idx,evict=(t_now>idx and not NOEVICT and c<8) if NOEVICT else t_now>idx,budget=bp,recent=recent,sink=sink,stride=stride,tova_head_mean=True,n_split=NSPLIT)
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e2=torch.cuda.Event(enable_timing=True)
     e0.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4],phases=1); e1.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4],phases=2); e2.record()
     ev.append((e0,e1,e2))
