@@ -96,11 +96,17 @@ def main():
     ap.add_argument("--no-handoff", action="store_true")
     ap.add_argument("--split-kernels", action="store_true", help="force the two-kernel path (attention + score/select)")
     ap.add_argument("--overlap-scorer", action="store_true", help="split path: run the scorer on side streams, off the critical path")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
+    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0 (multi-rank smoke test on a 1-GPU box)")
     ap.add_argument("--graph", action="store_true", help="capture one step (all launches) in a hipGraph and replay it")
     args = ap.parse_args()
 
     from easykv_amd import dist as DS
-    rank, local_rank, world = DS.init("nccl")
+    if args.same_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local_rank, world = DS.init(args.backend)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     shard = DS.LayerShard(rank, world, args.layers * world)   # weak scaling: every rank owns a block of `layers` layers
