@@ -9,27 +9,27 @@
 #include "ekv_common.h"
 #include "ekv_kernels.h"
 
-constexpr int kNW = 4;  // waves per workgroup
 constexpr int kU = 8;   // rows in flight per lane group (K and V each)
 
-template <int D>
+template <int D, int NW = 4>
 struct EkvDecodeGeom {
   static constexpr int LPR = D / 8;   // lanes per row
   static constexpr int G = 64 / LPR;  // rows per wave-load
   static constexpr int RW = G * kU;   // rows per wave per iteration
-  static constexpr int NP = kNW;      // partials per workgroup (lane groups are combined in-wave)
+  static constexpr int NP = NW;       // partials per workgroup = waves (lane groups are combined in-wave)
   static constexpr int PS = D + 2;    // (m, l, o[D])
 };
 
 // Streams positions [t0, t1) of KV head h.  SLOT_LDS: s_slot holds slot_of_pos[t0..t1) in LDS; otherwise s_slot is
 // the head's row of the global slot map (t0 must be a multiple of 8) and the 8 indices of a lane group are fetched
 // one iteration ahead.  Logits (q.k / sm_div) go to `logit_out` (+ `logit_stride` per query head): workspace or LDS.
-template <int D, int REP, bool ROPE, bool SLOT_LDS>
+template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4>
 __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
                                                   int logit_stride, int t0, int t1_in, int ll, int h, size_t head_row,
                                                   float (&m)[REP], float (&l)[REP], float (&o)[REP][8]) {
-  using Gm = EkvDecodeGeom<D>;
+  using Gm = EkvDecodeGeom<D, NW>;
   constexpr int LPR = Gm::LPR, RW = Gm::RW;
+  constexpr int kNW = NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int t_new = a.n_slots - 1;  // the appended position
@@ -218,10 +218,10 @@ __device__ __forceinline__ void ekv_decode_wave_combine(float (&m)[REP], float (
 }
 
 // Wave partials -> LDS (call after ekv_decode_wave_combine, then __syncthreads(), then ekv_decode_reduce).
-template <int D, int REP>
+template <int D, int REP, int NW = 4>
 __device__ __forceinline__ void ekv_decode_stash(float* s_part, const float (&m)[REP], const float (&l)[REP],
                                                  const float (&o)[REP][8]) {
-  using Gm = EkvDecodeGeom<D>;
+  using Gm = EkvDecodeGeom<D, NW>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % Gm::LPR, grp = lane / Gm::LPR;
   if (grp != 0) return;
@@ -238,9 +238,9 @@ __device__ __forceinline__ void ekv_decode_stash(float* s_part, const float (&m)
 }
 
 // Combined (max, sum, o[d]) of query head r over the workgroup's wave partials.
-template <int D, int REP>
+template <int D, int REP, int NW = 4>
 __device__ __forceinline__ void ekv_decode_reduce(const float* s_part, int r, int d, float& mm, float& ls, float& os) {
-  using Gm = EkvDecodeGeom<D>;
+  using Gm = EkvDecodeGeom<D, NW>;
   mm = EKV_NEG_INF;
 #pragma unroll
   for (int i = 0; i < Gm::NP; ++i) mm = fmaxf(mm, s_part[((size_t)i * REP + r) * Gm::PS]);

@@ -12,10 +12,11 @@
 #define EKV_STAMP(i) do { } while (0)
 #endif
 
-struct Red4 {  // block reductions for a 4-wave workgroup; scratch = 2 x 4 x 8 x 8 bytes
+template <int NW>
+struct RedN {  // block reductions for an NW-wave workgroup; scratch = 2 x NW x 8 x 8 bytes
   unsigned long long* buf;
   int phase, lane, wave;
-  __device__ __forceinline__ unsigned long long* slot() { return buf + (phase++ & 1) * 32; }
+  __device__ __forceinline__ unsigned long long* slot() { return buf + (phase++ & 1) * (NW * 8); }
   template <int N>
   __device__ __forceinline__ void max_n(float (&x)[N]) {
     float* r = reinterpret_cast<float*>(slot());
@@ -26,7 +27,12 @@ struct Red4 {  // block reductions for a 4-wave workgroup; scratch = 2 x 4 x 8 x
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = fmaxf(fmaxf(r[i], r[8 + i]), fmaxf(r[16 + i], r[24 + i]));
+    for (int i = 0; i < N; ++i) {
+      float y = r[i];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) y = fmaxf(y, r[w * 8 + i]);
+      x[i] = y;
+    }
   }
   template <int N>
   __device__ __forceinline__ void sum_n(float (&x)[N]) {
@@ -38,7 +44,12 @@ struct Red4 {  // block reductions for a 4-wave workgroup; scratch = 2 x 4 x 8 x
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = (r[i] + r[8 + i]) + (r[16 + i] + r[24 + i]);
+    for (int i = 0; i < N; ++i) {
+      float y = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) y += r[w * 8 + i];
+      x[i] = y;
+    }
   }
   __device__ __forceinline__ int sum_int(int x) {
 #pragma unroll
@@ -46,39 +57,39 @@ struct Red4 {  // block reductions for a 4-wave workgroup; scratch = 2 x 4 x 8 x
     int* r = reinterpret_cast<int*>(slot());
     if (lane == 0) r[wave] = x;
     __syncthreads();
-    return (r[0] + r[1]) + (r[2] + r[3]);
+    int y = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) y += r[w];
+    return y;
   }
   __device__ __forceinline__ unsigned long long min_u64(unsigned long long x) {
     x = ekv_wave_min_u64(x);
     unsigned long long* r = slot();
     if (lane == 0) r[wave] = x;
     __syncthreads();
-    const unsigned long long a = r[0] < r[1] ? r[0] : r[1], b = r[2] < r[3] ? r[2] : r[3];
-    return a < b ? a : b;
-  }
-  __device__ __forceinline__ uint32_t bcast_u32(bool owner, uint32_t v) {
-    uint32_t* r = reinterpret_cast<uint32_t*>(slot());
-    if (owner) r[0] = v;
-    __syncthreads();
-    return r[0];
+    unsigned long long y = r[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) y = r[w] < y ? r[w] : y;
+    return y;
   }
 };
-
+using Red4 = RedN<4>;
 
 // Score rows of (layer, head) -> LDS by asynchronous LDS-DMA (1 KiB per wave-instruction); the ragged end by plain
 // loads.  The data is complete after the caller's next __syncthreads() (vmcnt(0) precedes the barrier).
+template <int NW = 4>
 __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, size_t head_row, int W, int w_pad, bool roco,
                                                        float* sS, float* sQ, float* sC) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_arr = roco ? 3 : 1;
   const int full = W / 256;
-  for (int c = wave; c < full * n_arr; c += 4) {
+  for (int c = wave; c < full * n_arr; c += NW) {
     const int arr = c / full, ch = c % full;
     const float* src = (arr == 0 ? sc.score_sum : arr == 1 ? sc.score_sq : sc.score_cnt) + head_row + ch * 256 + lane * 4;
     float* dst = sS + (size_t)arr * w_pad + ch * 256;     // wave-uniform base; lane i lands at +16*i bytes
     __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
-  for (int j = full * 256 + tid; j < W; j += 256) {
+  for (int j = full * 256 + tid; j < W; j += 64 * NW) {
     sS[j] = sc.score_sum[head_row + j];
     if (roco) {
       sQ[j] = sc.score_sq[head_row + j];
@@ -87,10 +98,11 @@ __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, s
   }
 }
 
-template <int REP, int ITEMS>
+template <int REP, int ITEMS, int NW = 4>
 __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, int h, size_t head_row, int T, int off, int W,
-                                                float* s_logit, int t_pad, float* sS, float* sQ, float* sC, Red4& red) {
+                                                float* s_logit, int t_pad, float* sS, float* sQ, float* sC, RedN<NW>& red) {
   const int tid = threadIdx.x;
+  constexpr int NT = 64 * NW;
   const bool roco = sc.policy == EKV_POLICY_ROCO;
   const bool scored = roco || sc.policy == EKV_POLICY_H2O_HEAD || sc.policy == EKV_POLICY_TOVA;
 #ifdef EKV_TAIL_PROFILE
@@ -98,19 +110,19 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
 #endif
   EKV_STAMP(2);
   // ---- exact softmax of the row(s), GQA fold, accumulate into the LDS-resident rows (easykv/easykv.py:271-300) ----
-  // (every thread only ever touches its own columns j = tid + 256*it, so no barrier is needed between the phases)
+  // (every thread only ever touches its own columns j = tid + NT*it, so no barrier is needed between the phases)
   if (scored && sc.accumulate) {
     float mx[REP], sm[REP];
 #pragma unroll
     for (int r = 0; r < REP; ++r) mx[r] = EKV_NEG_INF, sm[r] = 0.f;
 #pragma unroll 4
-    for (int j = tid; j < T; j += 256) {
+    for (int j = tid; j < T; j += NT) {
 #pragma unroll
       for (int r = 0; r < REP; ++r) mx[r] = fmaxf(mx[r], s_logit[(size_t)r * t_pad + j]);
     }
-    red.max_n<REP>(mx);
+    red.template max_n<REP>(mx);
 #pragma unroll 4
-    for (int j = tid; j < T; j += 256) {      // e = exp(x - max) once: it replaces the logit in LDS
+    for (int j = tid; j < T; j += NT) {      // e = exp(x - max) once: it replaces the logit in LDS
 #pragma unroll
       for (int r = 0; r < REP; ++r) {
         const float e = expf(s_logit[(size_t)r * t_pad + j] - mx[r]);
@@ -118,11 +130,11 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
         sm[r] += e;
       }
     }
-    red.sum_n<REP>(sm);
-    // off + j == a column this thread wrote itself only when off % 256 == 0; otherwise wait for the other writers
-    if ((off & 255) != 0) __syncthreads();
+    red.template sum_n<REP>(sm);
+    // off + j == a column this thread wrote itself only when off % NT == 0; otherwise wait for the other writers
+    if ((off % NT) != 0) __syncthreads();
 #pragma unroll 4
-    for (int j = tid; j < W; j += 256) {
+    for (int j = tid; j < W; j += NT) {
       float pb = 0.f;
 #pragma unroll
       for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + off + j] / sm[r];
@@ -145,9 +157,9 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
     } else if (roco) {
       // std keys overwrite the (dead) first logit row at the thread's own columns
       uint32_t* kstd = reinterpret_cast<uint32_t*>(s_logit);
-      if ((off & 255) != 0) __syncthreads();   // all e's consumed before their cells are reused
+      if ((off % NT) != 0) __syncthreads();   // all e's consumed before their cells are reused
   #pragma unroll 4
-    for (int j = tid; j < W; j += 256) {
+    for (int j = tid; j < W; j += NT) {
         const float c = sC[j] + sc.count_add;
         sC[j] = c;
         const float mean = sS[j] / c;
@@ -165,7 +177,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
         if (victim >= 0) break;
         unsigned long long best = ~0ull;
     #pragma unroll 4
-    for (int j = tid; j < W; j += 256) {
+    for (int j = tid; j < W; j += NT) {
           bool dropped = false;
 #pragma unroll
           for (int i = 0; i < 8; ++i) dropped |= (i < attempt && excl[i] == j);
@@ -176,7 +188,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
         const uint32_t sk = kstd[cand];          // written before the barrier inside min_u64
         int c = 0;
 #pragma unroll 4
-        for (int j = tid; j < W; j += 256) c += (kstd[j] < sk || (kstd[j] == sk && j < cand)) ? 1 : 0;
+        for (int j = tid; j < W; j += NT) c += (kstd[j] < sk || (kstd[j] == sk && j < cand)) ? 1 : 0;
         if (red.sum_int(c) < sc.roco_k1) victim = cand;
         else excl[attempt] = cand;               // not feasible: drop it from the walk
       }
@@ -187,12 +199,12 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
           const uint32_t t = tau | (1u << bit);
           int c = 0;
   #pragma unroll 4
-        for (int j = tid; j < W; j += 256) c += kstd[j] < t ? 1 : 0;
+        for (int j = tid; j < W; j += NT) c += kstd[j] < t ? 1 : 0;
           if (red.sum_int(c) < sc.roco_k1) tau = t;
         }
         int c_less = 0, c_eq = 0;
     #pragma unroll 4
-    for (int j = tid; j < W; j += 256) {
+    for (int j = tid; j < W; j += NT) {
           c_less += kstd[j] < tau ? 1 : 0;
           c_eq += kstd[j] == tau ? 1 : 0;
         }
@@ -204,14 +216,14 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
             const int mid = (lo + hi) >> 1;
             int c = 0;
     #pragma unroll 4
-        for (int j = tid; j < W; j += 256) c += (kstd[j] == tau && j < mid) ? 1 : 0;
+        for (int j = tid; j < W; j += NT) c += (kstd[j] == tau && j < mid) ? 1 : 0;
             if (red.sum_int(c) >= need) hi = mid; else lo = mid + 1;
           }
           bound = lo;
         }
         unsigned long long best = ~0ull;
     #pragma unroll 4
-    for (int j = tid; j < W; j += 256) {
+    for (int j = tid; j < W; j += NT) {
           const bool feas = kstd[j] < tau || (kstd[j] == tau && j < bound);
           const unsigned long long x = ((unsigned long long)ekv_fkey(sS[j] / sC[j]) << 32) | (uint32_t)j;
           if (feas) best = x < best ? x : best;
@@ -220,7 +232,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
       }
     } else if (scored) {  // h2o_head / tova: argmin of the accumulated score inside the candidate window
       unsigned long long best = ~0ull;
-      for (int j = sc.win_lo + tid; j < W - sc.win_tail; j += 256) {
+      for (int j = sc.win_lo + tid; j < W - sc.win_tail; j += NT) {
         const unsigned long long x = ((unsigned long long)ekv_fkey(sS[j]) << 32) | (uint32_t)j;
         best = x < best ? x : best;
       }
@@ -232,7 +244,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
   // ---- write back: score rows (compacted past the victim), evict id, slot map ----------------------------
   if (scored && (sc.accumulate || victim >= 0)) {
 #pragma unroll 4
-    for (int j = tid; j < W; j += 256) {
+    for (int j = tid; j < W; j += NT) {
       if (j != victim) {
         const int d = j - ((victim >= 0 && j > victim) ? 1 : 0);
         sc.score_sum[head_row + d] = sS[j];
@@ -259,13 +271,13 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
     int moved[ITEMS + 1];
 #pragma unroll
     for (int it = 0; it <= ITEMS; ++it) {
-      const int p = pv + tid + it * 256;
+      const int p = pv + tid + it * NT;
       moved[it] = p < T ? map[p] : 0;
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it <= ITEMS; ++it) {
-      const int p = pv + tid + it * 256;
+      const int p = pv + tid + it * NT;
       if (p < T) map[p == pv ? T - 1 : p - 1] = moved[it];
     }
   }
