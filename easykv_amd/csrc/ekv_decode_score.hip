@@ -6,8 +6,13 @@
 
 namespace {
 
+#ifndef EKV_SCORE_NW
+#define EKV_SCORE_NW 8
+#endif
+constexpr int kSNW = EKV_SCORE_NW, kSNT = 64 * kSNW;   // waves / threads per scorer workgroup
+
 template <int REP, int ITEMS>
-__global__ void __launch_bounds__(256) ekv_decode_score_kernel(const EkvScoreArgs sc) {
+__global__ void __launch_bounds__(kSNT) ekv_decode_score_kernel(const EkvScoreArgs sc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int h = blockIdx.x, ll = blockIdx.y, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -21,7 +26,7 @@ __global__ void __launch_bounds__(256) ekv_decode_score_kernel(const EkvScoreArg
   float* sS = s_logit + (size_t)REP * t_pad;
   float* sQ = sS + w_pad;
   float* sC = sQ + w_pad;
-  Red4 red;
+  RedN<kSNW> red;
   red.buf = reinterpret_cast<unsigned long long*>(sS + (size_t)(roco ? 3 : 1) * w_pad);
   red.phase = 0;
   red.lane = lane;
@@ -29,26 +34,26 @@ __global__ void __launch_bounds__(256) ekv_decode_score_kernel(const EkvScoreArg
   const size_t head_row = ((size_t)(sc.layer_begin + ll) * sc.n_kv_heads + h) * sc.cap;
   const size_t hq0 = (size_t)ll * sc.n_q_heads + (size_t)h * REP;
 
-  if (scored) ekv_tail_prefetch_rows(sc, head_row, W, w_pad, roco, sS, sQ, sC);
+  if (scored) ekv_tail_prefetch_rows<kSNW>(sc, head_row, W, w_pad, roco, sS, sQ, sC);
   if (scored && sc.accumulate) {   // logits rows -> LDS (rows are 256-byte aligned in the workspace)
     const int full = t_pad / 256;
-    for (int c = wave; c < full * REP; c += 4) {
+    for (int c = wave; c < full * REP; c += kSNW) {
       const int r = c / full, ch = c % full;
       const float* src = sc.logits + (hq0 + r) * t_pad + ch * 256 + lane * 4;
       __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(s_logit + (size_t)r * t_pad + ch * 256), 16, 0, 0);
     }
     for (int r = 0; r < REP; ++r)
-      for (int j = full * 256 + tid; j < t_pad; j += 256) s_logit[(size_t)r * t_pad + j] = sc.logits[(hq0 + r) * t_pad + j];
+      for (int j = full * 256 + tid; j < t_pad; j += kSNT) s_logit[(size_t)r * t_pad + j] = sc.logits[(hq0 + r) * t_pad + j];
   }
 
   // fold the key-range splits into the attention output
   const int PS = D + 2;
-  for (int idx = tid; idx < (sc.skip_fold ? 0 : REP * D); idx += 256) {
+  for (int idx = tid; idx < (sc.skip_fold ? 0 : REP * D); idx += kSNT) {
     const int r = idx / D, d = idx % D;
     sc.out[(hq0 + r) * D + d] = __float2half(ekv_fold_partials(sc.partials + ((hq0 + r) * sc.n_split) * PS, sc.n_split, PS, d));
   }
   __syncthreads();   // LDS-DMA complete (vmcnt(0) before the barrier) and visible
-  ekv_decode_tail<REP, ITEMS>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red);
+  ekv_decode_tail<REP, ITEMS, kSNW>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red);
 }
 
 // Partials of the key-range splits -> fp16 attention output, nothing else (rows = q_len * n_q_heads per layer).
@@ -61,7 +66,7 @@ __global__ void __launch_bounds__(128) ekv_fold_kernel(const EkvScoreArgs sc) {
 
 size_t score_lds(int rep, int t_pad, int policy) {
   const size_t n_state = policy == EKV_POLICY_ROCO ? 3 : 1;
-  return ((size_t)rep * t_pad + n_state * ekv_align((size_t)t_pad, 256)) * 4 + 2 * 32 * 8;
+  return ((size_t)rep * t_pad + n_state * ekv_align((size_t)t_pad, 256)) * 4 + 2 * kSNW * 8 * 8;
 }
 
 template <int REP, int ITEMS>
@@ -70,13 +75,13 @@ hipError_t launch_k(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ekv_decode_score_kernel<REP, ITEMS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((ekv_decode_score_kernel<REP, ITEMS>), dim3(sc.n_kv_heads, layer_count), dim3(256), lds, s, sc);
+  hipLaunchKernelGGL((ekv_decode_score_kernel<REP, ITEMS>), dim3(sc.n_kv_heads, layer_count), dim3(kSNT), lds, s, sc);
   return hipGetLastError();
 }
 
 template <int REP>
 hipError_t launch_rep(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
-  return sc.n_slots <= 256 * 9 ? launch_k<REP, 9>(sc, layer_count, s) : launch_k<REP, 24>(sc, layer_count, s);
+  return sc.n_slots <= kSNT * (2304 / kSNT) ? launch_k<REP, 2304 / kSNT>(sc, layer_count, s) : launch_k<REP, 6144 / kSNT>(sc, layer_count, s);
 }
 
 }  // namespace
