@@ -189,3 +189,44 @@ def test_c4_shape_stride96_and_long_decode_rows():
         O.SELECT_HOOK = None
     assert bank.n_slots[0] == idx
     _check_permutation(bank)
+
+
+def test_baseline_config0_geometry_decoding_budget200():
+    """BASELINE.json configs[0]: decoding mode, budget=200, kv_policy='roco' (test_decoding.py:29-48 uses 300 / 150):
+    W = 201, recent = int(200*0.3) = 60, k1 = 140; Llama2-7B head shape, prompt of 37 tokens that is never evicted."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    H, D, P, budget, steps = 32, 128, 37, 200, 260
+    g = torch.Generator().manual_seed(200)
+    qs, ks, vs = (torch.randn(1, H, P + steps, D, generator=g).half() for _ in range(3))
+    bank = KVBank(1, H, H, D, cap=P + budget + 1)
+    bank.load_rows(ks[:, :, :P].cuda(), vs[:, :, :P].cuda())
+    bank.state_init(budget + 1, 0)
+    st = O.LayerState(k=ks[:, :, :P].float(), v=vs[:, :, :P].float())
+    st.s, st.q, st.c = O.init_state_decoding((H,), budget)
+    alive = torch.ones(H, dtype=torch.bool)
+    probe = Probe()
+    O.SELECT_HOOK = probe
+    n_dec = n_stable = 0
+    try:
+        for i in range(steps):
+            t = P + i
+            evict = (bank.n_slots[0] + 1 - P) > budget
+            kw = dict(policy="roco", phase="decode", evict=evict, score_off=P, budget=budget)
+            out, ids = bank.attend(StepPlan(n_split=i % 3, **kw), qs[:, :, t:t + 1].cuda().contiguous(), ks[:, :, t:t + 1].cuda().contiguous(),
+                                   vs[:, :, t:t + 1].cuda().contiguous())
+            o_ref, ids_ref = O.layer_step(st, qs[:, :, t:t + 1].float(), ks[:, :, t:t + 1].float(), vs[:, :, t:t + 1].float(), O.StepPlan(**kw))
+            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4)
+            if evict:
+                got = ids[0, :, 0].cpu().long() - P
+                ok = ~probe.last_unstable
+                same = got == ids_ref[:, 0]
+                n_dec += int(alive.sum())
+                n_stable += int((alive & ok).sum())
+                assert bool(same[alive & ok].all()), i
+                alive &= ok & same
+                assert int(got.min()) >= 0 and int(got.max()) < budget + 1 - O.ROCO_TAIL     # prompt and last 10 never evicted
+    finally:
+        O.SELECT_HOOK = None
+    assert bank.n_slots[0] == P + budget            # "KV cache budget ratio: ...(200/260)"
+    assert n_stable >= 0.9 * n_dec, (n_stable, n_dec)
