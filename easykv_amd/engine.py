@@ -51,6 +51,7 @@ class KVBank:
         if dev.type != "cuda":
             raise _lib.EkvError("KVBank needs a GPU device; the product path has no CPU fallback")
         self.device = dev
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         cap = (cap + 63) // 64 * 64     # rows of the slot map / score rows stay 16-byte aligned (fused kernel, LDS-DMA)
         self.n_layers, self.n_q_heads, self.n_kv_heads, self.head_dim, self.cap = n_layers, n_q_heads, n_kv_heads, head_dim, cap
         self.k = torch.empty(n_layers, n_kv_heads, cap, head_dim, dtype=torch.float16, device=dev)
@@ -76,7 +77,7 @@ class KVBank:
 
     # -- plumbing -----------------------------------------------------------------------------
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(torch.cuda.current_stream(self._dev_index).cuda_stream)
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
