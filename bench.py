@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--budget", type=int, default=2048)
     ap.add_argument("--policy", default="roco")
     ap.add_argument("--layers-per-launch", type=int, default=0, help="0 = all layers of the rank in one launch")
+    ap.add_argument("--n-split", type=int, default=0, help="key-range splits per head (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-handoff", action="store_true")
     ap.add_argument("--split-kernels", action="store_true", help="force the two-kernel path (attention + score/select)")
@@ -130,7 +131,7 @@ def main():
     vs = torch.randn(n_total, L, H, 1, D, generator=gen, device=dev).half()
     out = torch.empty(L, Hq, 1, D, dtype=torch.float16, device=dev)
     ids = torch.empty(L, H, 1, dtype=torch.int32, device=dev)
-    plan = StepPlan(policy=args.policy, phase="decode", evict=True, score_off=0, budget=budget)
+    plan = StepPlan(policy=args.policy, phase="decode", evict=True, score_off=0, budget=budget, n_split=args.n_split)
     if args.policy == "recency":
         plan.range_start = 0
     lpl = args.layers_per_launch or L
