@@ -80,9 +80,10 @@ __device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split,
     for (int i = 0; i < BATCH; ++i) {
       const bool ok = s0 + i < n_split;
       const float* p = p0 + (size_t)(ok ? s0 + i : 0) * PS;
-      mv[i] = ok ? p[0] : EKV_NEG_INF;
-      lv[i] = ok ? p[1] : 0.f;
-      ov[i] = ok ? p[2 + d] : 0.f;
+      const float pm = p[0], pl = p[1], po = p[2 + d];   // unconditional loads (clamped pointer), masked afterwards
+      mv[i] = ok ? pm : EKV_NEG_INF;
+      lv[i] = ok ? pl : 0.f;
+      ov[i] = ok ? po : 0.f;
     }
     float mb = mm;
 #pragma unroll
