@@ -272,7 +272,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
 #pragma unroll
     for (int it = 0; it <= ITEMS; ++it) {
       const int p = pv + tid + it * NT;
-      moved[it] = p < T ? map[p] : 0;
+      moved[it] = map[min(p, T - 1)];   // unconditional (clamped): predicated loads get serialised by hipcc
     }
     __syncthreads();
 #pragma unroll
