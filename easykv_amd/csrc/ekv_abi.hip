@@ -309,7 +309,9 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   if (err != hipSuccess) return EKV_E_LAUNCH;
   if (ph == 1) return EKV_OK;
 
-  if (ph & 4) {
+  if ((ph & 4) || (!scored && st->n_evict == 0 && !(ph & 8))) {
+    // nothing to score and nothing to evict ('full', or any unknown policy string): the step is the partial fold only,
+    // whatever the cache length
     if (ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
     if (!(ph & 8)) return EKV_OK;
   }

@@ -68,3 +68,28 @@ def test_argument_errors_are_reported():
         bank.attend(StepPlan(policy="full"), q, q, q)
     with pytest.raises(Exception):
         KVBank(1, 4, 4, 48, cap=64)     # unsupported head_dim
+
+
+def test_long_unbudgeted_cache_decode_and_chunk():
+    """kv_policy='full' over a 12k-slot cache (plain decode after an unbudgeted prefill, easykv/easykv.py:372-377, :508-526):
+    no score rows are involved, any length must work."""
+    import math
+    from easykv_amd import KVBank, StepPlan
+    L, Hq, H, D, T0 = 1, 8, 2, 128, 12000
+    g = torch.Generator().manual_seed(9)
+    k0, v0 = torch.randn(L, H, T0, D, generator=g).half().cuda(), torch.randn(L, H, T0, D, generator=g).half().cuda()
+    bank = KVBank(L, Hq, H, D, cap=T0 + 40, scored=False)
+    bank.load_rows(k0, v0)
+    for n in (1, 5):
+        q, k, v = (torch.randn(L, h, n, D, generator=g).half().cuda() for h in (Hq, H, H))
+        out, ids = bank.attend(StepPlan(policy="full", phase="decode" if n == 1 else "prefill", accumulate=False), q, k, v)
+        assert ids is None
+        kk, vv = bank.ordered_kv()
+        rep = Hq // H
+        w = (q.float() @ kk.float().repeat_interleave(rep, 1).transpose(2, 3)) / math.sqrt(D)
+        t = kk.shape[2]
+        mask = torch.ones(n, t, dtype=torch.bool, device="cuda").tril(diagonal=t - n)
+        w = w.masked_fill(~mask, float("-inf"))
+        ref = torch.softmax(w, -1) @ vv.float().repeat_interleave(rep, 1)
+        assert torch.allclose(out.float(), ref, atol=1e-3, rtol=1e-3), float((out.float() - ref).abs().max())
+    assert bank.n_slots[0] == T0 + 6
