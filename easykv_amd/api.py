@@ -275,7 +275,8 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                                   StepPlan(policy="full", phase="prefill", accumulate=False)).logits[:, -1, :]
         else:
             budget_p, idx, r_idx = geometry("encoding", length, budget, stride)
-            cache = new_cache(idx + stride + max_new_tokens)
+            # 'full' / unknown policy strings evict nothing (the reference's cache just grows): size for the whole prompt
+            cache = new_cache((idx + stride if evicting else length) + max_new_tokens)
             logits_last, _, _ = prefill(cache, budget_p, idx, r_idx, True)
         kept = cache.get_seq_length()
         print(f"KV cache budget ratio: {kept / length * 100:.2f}%({kept}/{length})")
@@ -318,7 +319,7 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
             result = math.exp(statistics.mean(lp))
         else:
             budget_p, idx, r_idx = geometry("ppl", length, budget, stride)
-            cache = new_cache(idx + stride)
+            cache = new_cache(idx + stride if evicting else length)
             _, all_logits, all_ids = prefill(cache, budget_p, idx, r_idx, True, keep_logits=True)
             kept = cache.get_seq_length()
             print(f"KV cache budget ratio: {kept / length * 100:.2f}%({kept}/{length})")

@@ -93,3 +93,33 @@ def test_long_unbudgeted_cache_decode_and_chunk():
         ref = torch.softmax(w, -1) @ vv.float().repeat_interleave(rep, 1)
         assert torch.allclose(out.float(), ref, atol=1e-3, rtol=1e-3), float((out.float() - ref).abs().max())
     assert bank.n_slots[0] == T0 + 6
+
+
+@pytest.mark.parametrize("hq,h,n,t_prev,n_split", [(32, 8, 64, 0, 0), (32, 8, 64, 192, 0), (8, 8, 200, 100, 0), (8, 4, 96, 300, 3),
+                                                  (16, 2, 40, 700, 2)])
+def test_scored_step_with_several_query_blocks(hq, h, n, t_prev, n_split):
+    """rep x q_len > 128 folded rows -> several query blocks per head.  A block that ends before the chunk does stops
+    at its own causal bound; the scorer must still see -inf (not stale workspace) on the positions after it — this is
+    the keep_attention prefix of a GQA model (64 queries x rep 4)."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    d = 64
+    g = torch.Generator().manual_seed(hq * 1000 + n)
+    T = t_prev + n
+    q = torch.randn(1, hq, n, d, generator=g).half()
+    k = torch.randn(1, h, T, d, generator=g).half()
+    v = torch.randn(1, h, T, d, generator=g).half()
+    bank = KVBank(1, hq, h, d, cap=T + 64)
+    if t_prev:
+        bank.load_rows(k[:, :, :t_prev].cuda(), v[:, :, :t_prev].cuda())
+    bank.state_init(T, 2, 1)
+    # poison whatever workspace the allocator hands out next with finite values
+    junk = torch.full((64 << 20,), 3.0, device="cuda")
+    del junk
+    out, _ = bank.attend(StepPlan(policy="roco", phase="prefill", accumulate=True, evict=False, n_split=n_split),
+                         q.cuda(), k[:, :, t_prev:].cuda().contiguous(), v[:, :, t_prev:].cuda().contiguous())
+    o_ref, p = O.attention_core(q.float(), k.float(), v.float(), O.causal_chunk_mask(n, T, torch.float32))
+    pb = O.gqa_fold(p, h, hq // h)[0]
+    assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4)
+    assert torch.allclose(bank.score_sum[0, :, :T].cpu(), pb.sum(dim=-2), rtol=2e-5, atol=1e-7)
+    assert torch.allclose(bank.score_sq[0, :, :T].cpu(), (pb ** 2).sum(dim=-2), rtol=2e-5, atol=1e-9)
