@@ -234,6 +234,15 @@ def cases():
         config=dict(budget=64, kv_policy="roco", max_new_tokens=120))
     add("enc_roco_d128_s8", mode="encoding", stride=8, length=160, dims=dict(L=1, Hq=4, H=4, D=128),
         config=dict(budget=0.5, kv_policy="roco", max_new_tokens=2))
+    # long scored prefixes / wide chunks: more than one query block per head in the HIP chunk kernel
+    add("enc_roco_gqa_s8_keep_long", mode="encoding", stride=8, length=400, dims=dict(L=2, Hq=8, H=2, D=32), arch="MistralForCausalLM",
+        config=dict(budget=0.5, kv_policy="roco", keep_attention=True, max_new_tokens=2))
+    add("enc_h2o_s8_keep_long", mode="encoding", stride=8, length=400, dims=dict(L=1, Hq=4, H=4, D=32),
+        config=dict(budget=0.5, kv_policy="h2o_head", keep_attention=True, max_new_tokens=2))
+    add("enc_roco_s160_wide_chunk", mode="encoding", stride=160, length=800, dims=dict(L=1, Hq=4, H=4, D=32),
+        config=dict(budget=0.5, kv_policy="roco", max_new_tokens=2))
+    add("ppl_tova_gqa_s40_stream", mode="ppl", stride=40, length=360, streaming=True, dims=dict(L=1, Hq=8, H=2, D=64), arch="MistralForCausalLM",
+        config=dict(budget=0.5, kv_policy="tova", streaming=True))
     return out
 
 
@@ -254,8 +263,14 @@ def main():
     E, LP, MP = _import_reference()
     core = reference_core(LP, MP)
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None     # regenerate just these cases
     summary = {}
+    if only and os.path.exists(os.path.join(OUT, "SUMMARY.json")):
+        with open(os.path.join(OUT, "SUMMARY.json")) as f:
+            summary = json.load(f)
     for case in cases():
+        if only and case["name"] not in only:
+            continue
         d = case["dims"]
         max_pos = case["length"] + case["config"].get("max_new_tokens", 0) + 8
         want_ties = case["name"].endswith("_ties")
