@@ -105,3 +105,126 @@ def test_random_chunk_runs(seed):
     m = bank.slot_of_pos[0].cpu().numpy()
     for h in range(H):
         assert np.array_equal(np.sort(m[h]), np.arange(bank.cap))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_wide_chunk_runs(seed):
+    """Chunks wide enough for several query blocks per head (rep x stride up to 1040 folded rows), optionally with
+    RoPE-on-read, two layers per launch; a scored step without eviction first (keep_attention style), then evicting steps."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    rng = np.random.default_rng(500 + seed)
+    D = int(rng.choice([32, 64, 128]))
+    H = int(rng.choice([1, 2, 3]))
+    rep = int(rng.choice([1, 2, 4, 8]))
+    Hq = H * rep
+    s = int(rng.choice([40, 64, 96, 130]))
+    idx = int(rng.integers(260, 900))
+    policy = str(rng.choice(["roco", "h2o_head", "tova"]))
+    n_split = int(rng.choice([0, 1, 2, 4]))
+    stream = bool(rng.integers(0, 2))
+    L = 2
+    budget_p, recent, sink = idx + int(rng.integers(0, s)), int(idx * 0.2), 4
+    g = torch.Generator().manual_seed(900 + seed)
+    t_prev = idx - s                      # one scored, non-evicting step brings the cache to idx
+    k0, v0 = _mk(L, H, t_prev, D, g), _mk(L, H, t_prev, D, g)
+    bank = KVBank(L, Hq, H, D, cap=idx + s)
+    cos = sin = None
+    if stream:
+        cos, sin = O.rope_tables(idx + s + 8, D)
+        bank.set_rope(cos, sin)
+    bank.load_rows(k0.cuda(), v0.cuda())
+    bank.state_init(idx + s, 2, s)
+    sts = []
+    for l in range(L):
+        st = O.LayerState(k=k0[l:l + 1].float(), v=v0[l:l + 1].float())
+        st.s, st.q, st.c = O.init_state_prefill((H,), idx, s, False)
+        sts.append(st)
+    probe = Probe()
+    O.SELECT_HOOK = probe
+    alive = torch.ones(L, dtype=torch.bool)
+    try:
+        for step in range(4):
+            q, k, v = _mk(L, Hq, s, D, g), _mk(L, H, s, D, g), _mk(L, H, s, D, g)
+            kw = dict(policy=policy, phase="prefill", accumulate=True, evict=step > 0, budget=budget_p, recent=recent, sink=sink, stride=s,
+                      tova_head_mean=bool(seed % 2), streaming=stream)
+            out, ids = bank.attend(StepPlan(n_split=n_split, **kw), q.cuda(), k.cuda(), v.cuda())
+            for l in range(L):
+                if not bool(alive[l]):
+                    continue
+                o_ref, ids_ref = O.layer_step(sts[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw), cos, sin)
+                assert torch.allclose(out[l].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4), (seed, step, l, D, H, rep, s, stream)
+                if step == 0:
+                    if policy != "tova":
+                        assert torch.allclose(bank.score_sum[l, :, :idx].cpu(), sts[l].s[:, :idx], rtol=3e-5, atol=1e-7), (seed, l)
+                    continue
+                got, ref = torch.sort(ids[l].cpu().long(), dim=-1)[0], torch.sort(ids_ref, dim=-1)[0]
+                ok = ~probe.last_unstable
+                assert bool((got == ref).all(dim=-1)[ok].all()), (seed, step, l, D, H, rep, s, policy, n_split, stream)
+                alive[l] &= bool(ok.all())
+    finally:
+        O.SELECT_HOOK = None
+    assert bank.n_slots == [idx] * L
+    m = bank.slot_of_pos.cpu().numpy()
+    for l in range(L):
+        for h in range(H):
+            assert np.array_equal(np.sort(m[l, h]), np.arange(bank.cap))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_long_decode_runs(seed):
+    """Budgeted decode at random LONG cache lengths (every ITEMS variant of the fused / decode-scorer kernels, key splits,
+    optional RoPE-on-read, a score offset), warm synthetic score state, a few evicting steps."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    rng = np.random.default_rng(700 + seed)
+    D = int(rng.choice([32, 64, 128]))
+    H = int(rng.choice([1, 2, 5]))
+    rep = int(rng.choice([1, 2, 4, 8]))
+    Hq = H * rep
+    P = int(rng.choice([0, 0, 7, 130]))
+    budget = int(rng.integers(300, 6000))
+    policy = str(rng.choice(["roco", "roco", "h2o_head", "tova"]))
+    n_split = int(rng.choice([0, 1, 1, 3]))
+    stream = bool(rng.integers(0, 2))
+    L = 2
+    T0 = P + budget
+    g = torch.Generator().manual_seed(300 + seed)
+    k0, v0 = _mk(L, H, T0, D, g), _mk(L, H, T0, D, g)
+    warm = torch.rand(L, H, budget + 1, generator=g) * 1e-3
+    bank = KVBank(L, Hq, H, D, cap=T0 + 1 + int(rng.integers(0, 70)))
+    cos = sin = None
+    if stream:
+        cos, sin = O.rope_tables(T0 + 16, D)
+        bank.set_rope(cos, sin)
+    bank.load_rows(k0.cuda(), v0.cuda())
+    bank.state_init(budget + 1, 0)
+    bank.score_sum[:, :, :budget + 1] += warm.cuda()
+    bank.score_sq[:, :, :budget + 1] += (warm ** 2).cuda()
+    sts = []
+    for l in range(L):
+        st = O.LayerState(k=k0[l:l + 1].float(), v=v0[l:l + 1].float())
+        st.s, st.q, st.c = O.init_state_decoding((H,), budget)
+        st.s += warm[l]
+        st.q += warm[l] ** 2
+        sts.append(st)
+    alive = torch.ones(L, H, dtype=torch.bool)
+    probe = Probe()
+    O.SELECT_HOOK = probe
+    try:
+        for i in range(5):
+            q, k, v = _mk(L, Hq, 1, D, g), _mk(L, H, 1, D, g), _mk(L, H, 1, D, g)
+            kw = dict(policy=policy, phase="decode", evict=True, score_off=P, budget=budget, streaming=stream)
+            out, ids = bank.attend(StepPlan(n_split=n_split, **kw), q.cuda(), k.cuda(), v.cuda())
+            for l in range(L):
+                if not bool(alive[l].all()):
+                    continue
+                o_ref, ids_ref = O.layer_step(sts[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw), cos, sin)
+                assert torch.allclose(out[l].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4), (seed, i, l, D, H, rep, budget, stream)
+                same = ids[l, :, 0].cpu().long() == ids_ref[:, 0] + P
+                ok = ~probe.last_unstable
+                assert bool(same[ok].all()), (seed, i, l, D, H, rep, policy, n_split, budget, P, stream)
+                alive[l] &= ok & same
+    finally:
+        O.SELECT_HOOK = None
+    assert bank.n_slots == [T0] * L
