@@ -296,7 +296,6 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   // without the fold (4 and 8 let the caller run the scorer on a side stream, off the critical path)
   const int ph = st->phases;
   if (ph < 0 || ph > 15 || ((ph & 2) && (ph & (4 | 8)))) return EKV_E_ARG;
-  if ((ph & (4 | 8)) && n != 1) return EKV_E_UNSUPPORTED;
   hipError_t err = hipSuccess;
   if (ph != 0 && !(ph & 1)) {
   } else if (n == 1) {
@@ -316,10 +315,6 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
     if (!(ph & 8)) return EKV_OK;
   }
   sa.skip_fold = (ph & 8) ? 1 : 0;
-  if (ph & 8) {
-    if (!ekv_decode_score_supported(sa)) return EKV_E_UNSUPPORTED;
-    return ekv_launch_decode_score(sa, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
-  }
   if (ekv_decode_score_supported(sa))   // decode steps: the fast scorer (same tail as the fused kernel)
     return ekv_launch_decode_score(sa, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   if (ekv_score_lds_bytes(sa) > 160 * 1024) return EKV_E_UNSUPPORTED;

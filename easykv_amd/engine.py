@@ -217,7 +217,7 @@ class KVBank:
             out = torch.empty(lc, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
         if st.n_evict > 0 and evict_ids is None:
             evict_ids = torch.empty(lc, self.n_kv_heads, st.n_evict, dtype=torch.int32, device=self.device)
-        if overlap_scorer and phases == 0 and n == 1 and not self.step_plan(plan, n, layer_begin, lc)[1]:
+        if overlap_scorer and phases == 0 and not self.step_plan(plan, n, layer_begin, lc)[1]:
             self._attend_overlapped(st, q, k_new, v_new, out, evict_ids, lc, layer_begin)
             for l in range(layer_begin, layer_begin + lc):
                 self.n_slots[l] = st.n_slots - st.n_evict

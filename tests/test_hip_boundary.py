@@ -123,3 +123,47 @@ def test_scored_step_with_several_query_blocks(hq, h, n, t_prev, n_split):
     assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4)
     assert torch.allclose(bank.score_sum[0, :, :T].cpu(), pb.sum(dim=-2), rtol=2e-5, atol=1e-7)
     assert torch.allclose(bank.score_sq[0, :, :T].cpu(), (pb ** 2).sum(dim=-2), rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,hq,h", [(1, 4, 4), (1, 8, 2), (8, 4, 4), (16, 8, 2)])
+def test_phase_split_and_side_stream_scorer_equal_the_whole_step(n, hq, h):
+    """ekv_step.phases: (attention + fold) then (scorer without fold) == the whole step, for decode and chunk steps; the
+    engine's overlap_scorer mode (scorer on a side stream, next attention waits for it) gives the same trajectory."""
+    from easykv_amd import KVBank, StepPlan
+    d, t0, steps = 64, 300, 6
+    g = torch.Generator().manual_seed(n * 100 + hq)
+    k0, v0 = torch.randn(2, h, t0, d, generator=g).half().cuda(), torch.randn(2, h, t0, d, generator=g).half().cuda()
+    qs = [torch.randn(2, hq, n, d, generator=g).half().cuda() for _ in range(steps)]
+    ks = [torch.randn(2, h, n, d, generator=g).half().cuda() for _ in range(steps)]
+    vs = [torch.randn(2, h, n, d, generator=g).half().cuda() for _ in range(steps)]
+    if n == 1:
+        kw = dict(policy="roco", phase="decode", evict=True, budget=t0, n_split=2)
+    else:
+        kw = dict(policy="roco", phase="prefill", accumulate=True, evict=True, budget=t0 + n, recent=30, sink=4, stride=n)
+    res = {}
+    for mode in ("whole", "phases", "overlap"):
+        bank = KVBank(2, hq, h, d, cap=t0 + n)
+        bank.load_rows(k0, v0)
+        if n == 1:
+            bank.state_init(t0 + 1, 0)
+        else:
+            bank.state_init(t0 + n, 2, n)
+        outs, idl = [], []
+        for i in range(steps):
+            if mode == "phases":
+                out = torch.empty(2, hq, n, d, dtype=torch.float16, device="cuda")
+                ids = torch.empty(2, h, n, dtype=torch.int32, device="cuda")
+                bank.attend(StepPlan(**kw), qs[i], ks[i], vs[i], out=out, evict_ids=ids, phases=1 | 4)
+                snap = out.clone()
+                bank.attend(StepPlan(**kw), qs[i], ks[i], vs[i], out=out, evict_ids=ids, phases=8)
+                assert torch.equal(snap, out)          # the scorer pass must not touch the folded output
+            else:
+                out, ids = bank.attend(StepPlan(**kw), qs[i], ks[i], vs[i], overlap_scorer=(mode == "overlap"))
+            outs.append(out)
+            idl.append(ids)
+        bank.join()
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(outs).clone(), torch.stack(idl).clone(), bank.slot_of_pos.clone(), bank.score_sum.clone())
+    for mode in ("phases", "overlap"):
+        for a, b in zip(res["whole"], res[mode]):
+            assert torch.equal(a, b), mode
