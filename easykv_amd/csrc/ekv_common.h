@@ -71,9 +71,12 @@ __device__ __forceinline__ uint32_t ekv_fkey(float x) {
 
 // Fold the key-range-split partials (m, l, o[D]) of one query row into o[d] / l.  All loads of a pass are issued
 // together (BATCH splits per round trip): a naive loop serialises one L2 round trip per split (~10 us for 17 splits).
+// `mm` / `ls` return the row's softmax statistics (max logit, sum of exp(logit - max)) over all splits.
 template <int BATCH = 32>
-__device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split, int PS, int d) {
-  float mm = EKV_NEG_INF, ls = 0.f, os = 0.f;
+__device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split, int PS, int d, float& mm, float& ls) {
+  mm = EKV_NEG_INF;
+  ls = 0.f;
+  float os = 0.f;
   for (int s0 = 0; s0 < n_split; s0 += BATCH) {
     float mv[BATCH], lv[BATCH], ov[BATCH];
 #pragma unroll
@@ -100,6 +103,12 @@ __device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split,
     mm = mb;
   }
   return os / ls;
+}
+
+template <int BATCH = 32>
+__device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split, int PS, int d) {
+  float mm, ls;
+  return ekv_fold_partials<BATCH>(p0, n_split, PS, d, mm, ls);
 }
 
 static inline __host__ __device__ size_t ekv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
