@@ -142,6 +142,11 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   off += ekv_align(rowsq * w.n_partials * (bank->head_dim + 2) * 4, 256);
   w.tova_row = reinterpret_cast<float*>(p + off);
   off += ekv_align((size_t)st->layer_count * w.t_pad * 4, 256);
+  w.q_rot = nullptr;
+  if (st->rope_on_read && st->q_len > 1) {
+    w.q_rot = reinterpret_cast<__half*>(p + off);
+    off += ekv_align(2 * rowsq * bank->head_dim * 2, 256);
+  }
   w.bytes = off;
   return w;
 }
@@ -239,6 +244,8 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.partials = ws.partials;
   aa.rope_cos = st->rope_on_read ? rope_cos : nullptr;
   aa.rope_sin = st->rope_on_read ? rope_sin : nullptr;
+  aa.q_rot_hi = ws.q_rot;
+  aa.q_rot_lo = ws.q_rot ? ws.q_rot + (size_t)st->layer_count * bank->n_q_heads * n * bank->head_dim : nullptr;
   aa.n_q_heads = bank->n_q_heads;
   aa.n_kv_heads = bank->n_kv_heads;
   aa.cap = bank->cap;

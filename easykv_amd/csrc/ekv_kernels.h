@@ -11,6 +11,7 @@ struct EkvWs {
   float* logits;    // [layer_count][Hq][q_len][t_pad]   raw q.k/sm_div of every live position
   float* partials;  // [layer_count][Hq][q_len][n_split][D+2]   (m, l, o[D]) per key-range split
   float* tova_row;  // [layer_count][t_pad]   head-averaged last-query row (tova_head_mean)
+  __half* q_rot;    // rope_on_read chunk steps: [2][layer_count][Hq][q_len][D] rotated queries, fp16 hi then lo
   int32_t t_pad, n_split, rows_per_split;
   int32_t n_partials;   // partials per query row the scorer folds (chunk kernels emit 2 per split)
   int32_t qb_rows, n_qblocks;
@@ -30,6 +31,8 @@ struct EkvAttnArgs {
   float* partials;
   const float* rope_cos;
   const float* rope_sin;
+  __half* q_rot_hi;  // chunk kernels with rope_on_read: queries rotated by ekv_rope_q_kernel (hi + lo fp16 pair)
+  __half* q_rot_lo;
   int32_t n_q_heads, n_kv_heads, cap, n_slots, q_len, n_split, rows_per_split, t_pad, layer_begin, causal;
   int32_t qb_rows, n_qblocks;  // chunk kernels: queries per query block, number of query blocks
   float sm_div;

@@ -2,7 +2,9 @@ import sys, time, torch
 sys.path.insert(0,'.')
 from easykv_amd import KVBank, StepPlan, geometry
 L,Hq,H,D = 32,32,int(sys.argv[2]) if len(sys.argv)>2 else 32,128
-S, stride, budget = 4096, int(sys.argv[1]) if len(sys.argv)>1 else 8, 0.5
+import os
+S, stride, budget = int(os.environ.get('S','4096')), int(sys.argv[1]) if len(sys.argv)>1 else 8, float(os.environ.get('BUDGET','0.5'))
+STREAM = os.environ.get('STREAM','0')=='1'
 NSPLIT = int(sys.argv[3]) if len(sys.argv)>3 else 0
 import os
 POLICY = os.environ.get('POLICY','roco'); NOEVICT = os.environ.get('NOEVICT','0')=='1'
@@ -10,12 +12,15 @@ bp, idx, r_idx = geometry("encoding", S, budget, stride)
 recent, sink = int(bp*0.1), 4
 dev=torch.device('cuda'); g=torch.Generator(device=dev).manual_seed(0)
 bank=KVBank(L,Hq,H,D,cap=idx+stride)
+if STREAM:
+    from easykv_amd.api import rope_tables
+    bank.set_rope(*rope_tables(idx+stride+8, D))
 def rnd(h,n): return torch.randn(L,h,n,D,generator=g,device=dev).half()
 # dense prefix, layer blocks of 8 to bound the workspace
 torch.cuda.synchronize(); t0=time.perf_counter()
 for l0 in range(0,L,8):
     q,k,v = (x[l0:l0+8].contiguous() for x in (rnd(Hq,r_idx),rnd(H,r_idx),rnd(H,r_idx)))
-    bank.attend(StepPlan(policy='full',phase='prefill',accumulate=False), q,k,v, layer_begin=l0)
+    bank.attend(StepPlan(policy='full',phase='prefill',accumulate=False,streaming=STREAM), q,k,v, layer_begin=l0)
 torch.cuda.synchronize(); t_prefix=time.perf_counter()-t0
 bank.state_init(idx+stride,2,stride)
 n_chunks=(S-r_idx)//stride
@@ -25,7 +30,7 @@ torch.cuda.synchronize(); t0=time.perf_counter()
 for c in range(n_chunks):
     t_now=bank.n_slots[0]+stride
     if NOEVICT and t_now+stride>bank.cap: break
-    plan=StepPlan(policy=POLICY,phase='prefill',accumulate=t_now>idx,evict=(t_now>idx and not NOEVICT and c<8) if NOEVICT else t_now>idx,budget=bp,recent=recent,sink=sink,stride=stride,tova_head_mean=True,n_split=NSPLIT)
+    plan=StepPlan(streaming=STREAM,policy=POLICY,phase='prefill',accumulate=t_now>idx,evict=(t_now>idx and not NOEVICT and c<8) if NOEVICT else t_now>idx,budget=bp,recent=recent,sink=sink,stride=stride,tova_head_mean=True,n_split=NSPLIT)
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True); e2=torch.cuda.Event(enable_timing=True)
     e0.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4],phases=1); e1.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4],phases=2); e2.record()
     ev.append((e0,e1,e2))
