@@ -30,7 +30,7 @@ class Step(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "layer_begin", "layer_count", "q_len", "n_slots", "score_off", "policy", "accumulate", "n_evict",
         "win_lo", "win_tail", "roco_k1", "roco_tail", "range_start", "tova_head_mean", "causal", "rope_on_read",
-        "n_split", "phases")] + [(n, C.c_float) for n in ("count_add", "count_tail_step", "sm_div", "reserved_f")]
+        "n_split", "phases")] + [(n, C.c_float) for n in ("count_add", "count_tail_step", "sm_div")] + [("two_pass", C.c_int32)]
 
 
 class EkvError(RuntimeError):

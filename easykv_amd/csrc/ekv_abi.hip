@@ -134,7 +134,15 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   size_t off = 0;
   char* p = static_cast<char*>(base);
   w.logits = nullptr;
-  if (scored && st->accumulate) {   // the scorer only needs the logits when it accumulates
+  w.stats = w.colsum = nullptr;
+  w.two_pass = ekv_chunk_two_pass(rep, st->q_len, st->policy, scored, st->accumulate != 0, T - (scored ? st->score_off : 0), st->two_pass) ? 1 : 0;
+  w.n_col_parts = (qpw == 4 ? 4 : 2) * w.n_qblocks;   // query-tile waves per workgroup x query blocks
+  if (w.two_pass) {   // statistics partials + column sums instead of the logits
+    w.stats = reinterpret_cast<float*>(p + off);
+    off += ekv_align(rowsq * w.n_partials * 2 * 4, 256);
+    w.colsum = reinterpret_cast<float*>(p + off);
+    off += ekv_align((size_t)st->layer_count * bank->n_kv_heads * w.n_col_parts * 2 * w.t_pad * 4, 256);
+  } else if (scored && st->accumulate) {   // the scorer only needs the logits when it accumulates
     w.logits = reinterpret_cast<float*>(p + off);
     off += ekv_align(rowsq * w.t_pad * 4, 256);
   }
@@ -246,6 +254,9 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.rope_sin = st->rope_on_read ? rope_sin : nullptr;
   aa.q_rot_hi = ws.q_rot;
   aa.q_rot_lo = ws.q_rot ? ws.q_rot + (size_t)st->layer_count * bank->n_q_heads * n * bank->head_dim : nullptr;
+  aa.stats = ws.stats;
+  aa.colsum = ws.colsum;
+  aa.n_col_parts = ws.n_col_parts;
   aa.n_q_heads = bank->n_q_heads;
   aa.n_kv_heads = bank->n_kv_heads;
   aa.cap = bank->cap;
@@ -268,6 +279,8 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   sa.logits = ws.logits;
   sa.partials = ws.partials;
   sa.tova_row = ws.tova_row;
+  sa.colsum = ws.colsum;
+  sa.n_col_parts = ws.n_col_parts;
   sa.out = static_cast<__half*>(out);
   sa.evict_ids = evict_ids;
   sa.n_q_heads = bank->n_q_heads;
@@ -310,7 +323,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
     err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
   } else {
     if (!ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
-    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, s);
+    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, ws.two_pass != 0, s);
   }
   if (err != hipSuccess) return EKV_E_LAUNCH;
   if (ph == 1) return EKV_OK;

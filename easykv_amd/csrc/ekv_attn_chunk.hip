@@ -2,15 +2,30 @@
 #include "ekv_common.h"
 #include "ekv_kernels.h"
 
-hipError_t ekv_launch_attn_chunk_d32(const EkvAttnArgs&, int, int, hipStream_t);
-hipError_t ekv_launch_attn_chunk_d64(const EkvAttnArgs&, int, int, hipStream_t);
-hipError_t ekv_launch_attn_chunk_d128(const EkvAttnArgs&, int, int, hipStream_t);
+#define EKV_DECL(d, m) hipError_t ekv_launch_attn_chunk_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t);
+EKV_DECL(32, 0) EKV_DECL(32, 1) EKV_DECL(32, 2) EKV_DECL(64, 0) EKV_DECL(64, 1) EKV_DECL(64, 2)
+EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
+#undef EKV_DECL
+
+// Two-pass scheme (statistics pass + exact pass with in-kernel column sums, see ekv_attn_chunk.inc) for scored chunk
+// steps.  It trades one extra read of K for the rep x n x T logits never touching HBM.  Measured on MI355X (DESIGN.md
+// §8): the one-pass kernel + logits wins while the scorer keeps >= 2 workgroups per CU; once the score rows alone need
+// more than half of the LDS (W > ~4800) the scorer's pass over the logits falls off a cliff and two passes win.
+// tova needs the last query row itself, not column sums, and always stays on the one-pass kernel.
+bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, int width, int mode) {
+  const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // rep query heads share a 16-lane row
+  const bool can = q_len > 1 && scored && accumulate && policy != EKV_POLICY_TOVA && rep_ok;
+  if (!can || mode < 0) return false;
+  if (mode > 0) return true;
+  return rep * q_len >= 32 && (size_t)width * 16 > 76 * 1024;
+}
 
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len) {
   return (head_dim == 32 || head_dim == 64 || head_dim == 128) && rep >= 1 && rep <= 128 && q_len >= 1;
 }
 
-// A query block is <= 128 GQA-folded rows (rep x qb_rows); qpw = query tiles per wave.
+// A query block is <= 128 GQA-folded rows (rep x qb_rows).  qpw = 1 or 2: 16-row query tiles per wave of a 4-wave
+// workgroup (<= 32 / <= 64 rows); qpw = 4 selects the 8-wave workgroup (2 tiles per wave x 4 query-tile waves, <= 128 rows).
 void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw) {
   int rows = q_len;
   if (rep * q_len > 128) rows = 128 / rep > 0 ? 128 / rep : 1;
@@ -37,7 +52,7 @@ __global__ void __launch_bounds__(128) ekv_rope_q_kernel(const EkvAttnArgs a, in
   }
 }
 
-hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, hipStream_t s) {
+hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s) {
   if (a.rope_cos != nullptr) {
     if (a.q_rot_hi == nullptr || a.q_rot_lo == nullptr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ekv_rope_q_kernel, dim3(a.n_q_heads * a.q_len, layer_count), dim3(128), 0, s, a, head_dim);
@@ -45,10 +60,15 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
   if (qb_rows != a.qb_rows || n_qblocks != a.n_qblocks) return hipErrorInvalidValue;
+  if (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts != (qpw == 4 ? 4 : 2) * n_qblocks)) return hipErrorInvalidValue;
+#define EKV_GO(d, m) ekv_launch_attn_chunk_d##d##_m##m(a, qpw, layer_count, s)
+  hipError_t e = hipSuccess;
   switch (head_dim) {
-    case 32: return ekv_launch_attn_chunk_d32(a, qpw, layer_count, s);
-    case 64: return ekv_launch_attn_chunk_d64(a, qpw, layer_count, s);
-    case 128: return ekv_launch_attn_chunk_d128(a, qpw, layer_count, s);
-    default: return hipErrorInvalidValue;
+    case 32: e = two_pass ? EKV_GO(32, 1) : EKV_GO(32, 0); if (two_pass && e == hipSuccess) e = EKV_GO(32, 2); break;
+    case 64: e = two_pass ? EKV_GO(64, 1) : EKV_GO(64, 0); if (two_pass && e == hipSuccess) e = EKV_GO(64, 2); break;
+    case 128: e = two_pass ? EKV_GO(128, 1) : EKV_GO(128, 0); if (two_pass && e == hipSuccess) e = EKV_GO(128, 2); break;
+    default: e = hipErrorInvalidValue;
   }
+#undef EKV_GO
+  return e;
 }

@@ -11,6 +11,9 @@ struct EkvWs {
   float* logits;    // [layer_count][Hq][q_len][t_pad]   raw q.k/sm_div of every live position
   float* partials;  // [layer_count][Hq][q_len][n_split][D+2]   (m, l, o[D]) per key-range split
   float* tova_row;  // [layer_count][t_pad]   head-averaged last-query row (tova_head_mean)
+  float* stats;     // two-pass chunk steps (see EkvAttnArgs)
+  float* colsum;
+  int32_t two_pass, n_col_parts;
   __half* q_rot;    // rope_on_read chunk steps: [2][layer_count][Hq][q_len][D] rotated queries, fp16 hi then lo
   int32_t t_pad, n_split, rows_per_split;
   int32_t n_partials;   // partials per query row the scorer folds (chunk kernels emit 2 per split)
@@ -33,6 +36,9 @@ struct EkvAttnArgs {
   const float* rope_sin;
   __half* q_rot_hi;  // chunk kernels with rope_on_read: queries rotated by ekv_rope_q_kernel (hi + lo fp16 pair)
   __half* q_rot_lo;
+  float* stats;      // two-pass chunk steps: [layer_count][Hq][q_len][2*n_split][2] (max, sum exp) per key-range half split
+  float* colsum;     // two-pass chunk steps: [layer_count][H][n_col_parts][2][t_pad] column sums of pbar and pbar^2
+  int32_t n_col_parts;   // = query-tile waves per workgroup (2 or 4) * n_qblocks
   int32_t n_q_heads, n_kv_heads, cap, n_slots, q_len, n_split, rows_per_split, t_pad, layer_begin, causal;
   int32_t qb_rows, n_qblocks;  // chunk kernels: queries per query block, number of query blocks
   float sm_div;
@@ -45,6 +51,8 @@ struct EkvScoreArgs {
   float* score_cnt;
   const float* logits;
   const float* partials;
+  const float* colsum;   // non-null: column sums from the two-pass chunk kernel replace the logits
+  int32_t n_col_parts;
   float* tova_row;
   __half* out;
   int32_t* evict_ids;
@@ -58,7 +66,8 @@ struct EkvScoreArgs {
 EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* step, void* base);
 
 hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_count, hipStream_t s);
-hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, hipStream_t s);
+hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s);
+bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, int width, int mode);
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 bool ekv_attn_decode_supported(int head_dim, int rep);

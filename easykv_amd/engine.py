@@ -36,6 +36,7 @@ class StepPlan:
     range_start: int = -1       # recency / random
     streaming: bool = False
     n_split: int = 0
+    two_pass: int = 0           # scored chunk steps: 0 auto, 1 force the two-pass kernels, -1 force one pass
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -44,6 +45,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class KVBank:
     """K/V rows + slot map + score rows of ``n_layers`` layers on one GPU."""
+
+    default_two_pass = 0    # StepPlan.two_pass used when a plan leaves it at 0 (tests force either chunk scheme with it)
 
     def __init__(self, n_layers, n_q_heads, n_kv_heads, head_dim, cap, device="cuda", scored=True):
         self.lib = _lib.load()
@@ -138,6 +141,7 @@ class KVBank:
         st.causal = 1
         st.rope_on_read = int(plan.streaming)
         st.n_split = plan.n_split
+        st.two_pass = plan.two_pass or KVBank.default_two_pass
         st.sm_div = math.sqrt(self.head_dim)
         st.tova_head_mean = int(plan.tova_head_mean)
         st.roco_tail = ROCO_TAIL

@@ -93,7 +93,8 @@ typedef struct ekv_step {
   float count_add;      /* added to C before selection (1 decode, stride prefill); 0 = leave             */
   float count_tail_step;/* C tail after compaction: tail[i] = i * count_tail_step (0 decode, -1 prefill) */
   float sm_div;         /* logits are divided by this (sqrt(head_dim))                                   */
-  float reserved_f;
+  int32_t two_pass;     /* scored chunk steps: 0 = library decides, 1 = statistics pass + exact pass with in-kernel
+                           column sums whenever the shape allows it, -1 = always one pass with exported logits     */
 } ekv_step;
 
 int ekv_abi_version(void);

@@ -97,7 +97,8 @@ def test_long_unbudgeted_cache_decode_and_chunk():
 
 @pytest.mark.parametrize("hq,h,n,t_prev,n_split", [(32, 8, 64, 0, 0), (32, 8, 64, 192, 0), (8, 8, 200, 100, 0), (8, 4, 96, 300, 3),
                                                   (16, 2, 40, 700, 2)])
-def test_scored_step_with_several_query_blocks(hq, h, n, t_prev, n_split):
+@pytest.mark.parametrize("two_pass", [-1, 1])
+def test_scored_step_with_several_query_blocks(hq, h, n, t_prev, n_split, two_pass):
     """rep x q_len > 128 folded rows -> several query blocks per head.  A block that ends before the chunk does stops
     at its own causal bound; the scorer must still see -inf (not stale workspace) on the positions after it — this is
     the keep_attention prefix of a GQA model (64 queries x rep 4)."""
@@ -116,7 +117,7 @@ def test_scored_step_with_several_query_blocks(hq, h, n, t_prev, n_split):
     # poison whatever workspace the allocator hands out next with finite values
     junk = torch.full((64 << 20,), 3.0, device="cuda")
     del junk
-    out, _ = bank.attend(StepPlan(policy="roco", phase="prefill", accumulate=True, evict=False, n_split=n_split),
+    out, _ = bank.attend(StepPlan(policy="roco", phase="prefill", accumulate=True, evict=False, n_split=n_split, two_pass=two_pass),
                          q.cuda(), k[:, :, t_prev:].cuda().contiguous(), v[:, :, t_prev:].cuda().contiguous())
     o_ref, p = O.attention_core(q.float(), k.float(), v.float(), O.causal_chunk_mask(n, T, torch.float32))
     pb = O.gqa_fold(p, h, hq // h)[0]

@@ -20,8 +20,17 @@ def _cases():
     return [n for n in golden_names() if load_golden(n)["meta"]["tie_free"]]
 
 
+@pytest.fixture(params=[0, 1], ids=["auto", "two_pass"])
+def chunk_scheme(request):
+    """Every golden case also runs with the two-pass chunk kernels forced wherever a step is eligible."""
+    from easykv_amd.engine import KVBank
+    KVBank.default_two_pass = request.param
+    yield request.param
+    KVBank.default_two_pass = 0
+
+
 @pytest.mark.parametrize("name", _cases())
-def test_generate_matches_reference(name):
+def test_generate_matches_reference(name, chunk_scheme):
     import easykv_amd
     from tests.native_fake_model import NativeFakeModel
     g = load_golden(name)

@@ -107,10 +107,12 @@ def test_random_chunk_runs(seed):
         assert np.array_equal(np.sort(m[h]), np.arange(bank.cap))
 
 
+@pytest.mark.parametrize("two_pass", [-1, 1])
 @pytest.mark.parametrize("seed", range(10))
-def test_random_wide_chunk_runs(seed):
+def test_random_wide_chunk_runs(seed, two_pass):
     """Chunks wide enough for several query blocks per head (rep x stride up to 1040 folded rows), optionally with
-    RoPE-on-read, two layers per launch; a scored step without eviction first (keep_attention style), then evicting steps."""
+    RoPE-on-read, two layers per launch; a scored step without eviction first (keep_attention style), then evicting steps.
+    Both chunk schemes: one pass + exported logits (two_pass=-1) and statistics pass + exact pass (two_pass=1)."""
     from easykv_amd import KVBank, StepPlan
     from oracle import easykv_oracle as O
     rng = np.random.default_rng(500 + seed)
@@ -148,7 +150,7 @@ def test_random_wide_chunk_runs(seed):
             q, k, v = _mk(L, Hq, s, D, g), _mk(L, H, s, D, g), _mk(L, H, s, D, g)
             kw = dict(policy=policy, phase="prefill", accumulate=True, evict=step > 0, budget=budget_p, recent=recent, sink=sink, stride=s,
                       tova_head_mean=bool(seed % 2), streaming=stream)
-            out, ids = bank.attend(StepPlan(n_split=n_split, **kw), q.cuda(), k.cuda(), v.cuda())
+            out, ids = bank.attend(StepPlan(n_split=n_split, two_pass=two_pass, **kw), q.cuda(), k.cuda(), v.cuda())
             for l in range(L):
                 if not bool(alive[l]):
                     continue
