@@ -80,6 +80,48 @@ def cpu_baseline(args, budget, policy, seconds=12.0):
                        f"{policy}; per-token = {args.layers} x mean layer-step ({el / n_ls * 1e3:.2f} ms)")
 
 
+def strided_prefill(args, dev, n_chunks=24, warm=4):
+    """Secondary figure (never `value`): BASELINE.json configs[1] — the chunk phase of a strided prefill, S=4096, stride 8,
+    budget 0.5, kv_policy roco (SURVEY.md §8d Bench-P): the cache oscillates idx <-> idx+stride, every chunk step attends
+    the retained slots with 8 queries per head, scores and evicts 8 slots per (layer, head); all layers in one launch pair."""
+    from easykv_amd import KVBank, StepPlan, geometry
+    L, Hq, D = args.layers, args.heads, args.head_dim
+    H = args.kv_heads or Hq
+    S, stride = 4096, 8
+    bp, idx, r_idx = geometry("encoding", S, 0.5, stride)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    rnd = lambda h, n: torch.randn(L, h, n, D, generator=g, device=dev).half()
+    bank = KVBank(L, Hq, H, D, cap=idx + stride, device=dev)
+    bank.load_rows(rnd(H, idx), rnd(H, idx))          # state after the dense prefix and the fill-up chunks
+    bank.state_init(idx + stride, 2, stride)
+    q, k, v = rnd(Hq, stride), rnd(H, stride), rnd(H, stride)
+    plan = StepPlan(policy=args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco", phase="prefill", accumulate=True, evict=True,
+                    budget=bp, recent=int(bp * 0.1), sink=4, stride=stride, tova_head_mean=True)
+    out = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
+    ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
+    ev = []
+    for i in range(warm + n_chunks):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        bank.attend(plan, q, k, v, out=out, evict_ids=ids, phases=1)     # chunk attention kernel
+        e[1].record()
+        bank.attend(plan, q, k, v, out=out, evict_ids=ids, phases=2)     # fold + score + select + compaction
+        e[2].record()
+        if i >= warm:
+            ev.append(e)
+    torch.cuda.synchronize(dev)
+    t_attn = sum(a.elapsed_time(b) for a, b, _ in ev) / len(ev) * 1e-3
+    t_score = sum(b.elapsed_time(c) for _, b, c in ev) / len(ev) * 1e-3
+    T = idx + stride
+    n_state = {"roco": 3, "h2o_head": 1, "tova": 1}[plan.policy]
+    by = algorithmic_bytes(H, Hq, D, T, stride, n_state)
+    return {"workload": f"bench-P chunk phase: S={S} stride={stride} budget=0.5 -> idx={idx}, T={T}, L={L} Hq={Hq} H={H} D={D} kv_policy={plan.policy}",
+            "value": stride / (t_attn + t_score), "unit": "prompt tokens/s (chunk phase, attention/eviction path only)",
+            "us_per_chunk_step": (t_attn + t_score) * 1e6, "attn_kernel_us": t_attn * 1e6, "score_select_us": t_score * 1e6,
+            "algorithmic_bytes_per_step": by["total"] * L, "achieved_gbs": by["total"] * L / (t_attn + t_score) / 1e9,
+            "frac_of_hbm_peak": by["total"] * L / (t_attn + t_score) / 1e9 / HBM_PEAK_GBS, "chunk_steps_timed": len(ev)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +136,7 @@ def main():
     ap.add_argument("--layers-per-launch", type=int, default=0, help="0 = all layers of the rank in one launch")
     ap.add_argument("--n-split", type=int, default=0, help="key-range splits per head (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the secondary strided-prefill (configs[1]) figure")
     ap.add_argument("--no-handoff", action="store_true")
     ap.add_argument("--split-kernels", action="store_true", help="force the two-kernel path (attention + score/select)")
     ap.add_argument("--overlap-scorer", action="store_true", help="split path: run the scorer on side streams, off the critical path")
@@ -260,6 +303,8 @@ def main():
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
                                      "bytes_per_step_launches": b["total"] * lc0, "avg_us": (t_attn + t_score) * 1e6,
                                      "score_select_us": t_score * 1e6}
+        if world == 1 and not args.no_prefill and not args.graph:
+            line["strided_prefill"] = strided_prefill(args, dev)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, budget, args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco")
         print(json.dumps(line))
