@@ -80,6 +80,22 @@ def cpu_baseline(args, budget, policy, seconds=12.0):
                        f"{policy}; per-token = {args.layers} x mean layer-step ({el / n_ls * 1e3:.2f} ms)")
 
 
+def device_copy_gbs(dev, nbytes=1 << 30, iters=8):
+    """Measured device-to-device copy bandwidth (read + write bytes / time), the practical ceiling SURVEY.md §8d asks to be
+    reported next to the 8 TB/s spec."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.zero_()
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def strided_prefill(args, dev, n_chunks=24, warm=4):
     """Secondary figure (never `value`): BASELINE.json configs[1] — the chunk phase of a strided prefill, S=4096, stride 8,
     budget 0.5, kv_policy roco (SURVEY.md §8d Bench-P): the cache oscillates idx <-> idx+stride, every chunk step attends
@@ -290,6 +306,9 @@ def main():
             line["roofline"] = {"bound": "hbm", "kernel": "ekv_decode_fused_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                 "bytes_per_launch": b["total"] * lc0, "avg_launch_us": t_attn * 1e6}
+            copy = device_copy_gbs(dev)
+            line["roofline"]["device_copy_gbs"] = copy      # measured read+write copy bandwidth of this GPU
+            line["roofline"]["frac_of_device_copy"] = gbs / copy
         elif args.overlap_scorer:
             line["roofline"] = None     # kernels of different layers overlap: per-kernel event timing is not meaningful here
         else:
