@@ -69,3 +69,40 @@ def test_product_path_has_no_cpu_fallback():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_set_dynamicntk_rope_length_fixes_the_ntk_base():
+    """easykv/utils.py:53-57 on transformers >= 5: after the call the rotary module uses the NTK base of ``max_length``
+    for short AND long position ids (no recompute on growth up to max_length, no reset for short sequences)."""
+    import contextlib
+    import io
+    transformers = pytest.importorskip("transformers")
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    import easykv_amd
+    d, base, factor, orig, max_length = 16, 10000.0, 2.0, 64, 256
+    cfg = LlamaConfig(hidden_size=64, num_attention_heads=4, num_hidden_layers=1, intermediate_size=64, vocab_size=32,
+                      max_position_embeddings=orig, rope_parameters=dict(rope_type="dynamic", factor=factor, rope_theta=base))
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.rotary_emb = LlamaRotaryEmbedding(cfg)
+    m = Holder()
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        easykv_amd.set_dynamicntk_rope_length(m, max_length)
+    assert buf.getvalue().strip() == f"DynamicNTKRoPE max length reset to {max_length}"
+    ntk_base = base * ((factor * max_length / orig) - (factor - 1)) ** (d / (d - 2))
+    inv = 1.0 / (ntk_base ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+    x = torch.zeros(1, 1, d)
+    for n in (8, 200, 8):                                 # short, long (< max_length), short again
+        pos = torch.arange(n).view(1, -1)
+        cos, sin = m.rotary_emb(x, pos)
+        ref = torch.outer(torch.arange(n, dtype=torch.float32), inv)
+        assert torch.allclose(cos[0, :, : d // 2], ref.cos(), atol=1e-5), n
+        assert torch.allclose(sin[0, :, : d // 2], ref.sin(), atol=1e-5), n
+    with pytest.raises(ValueError):
+        easykv_amd.set_dynamicntk_rope_length(torch.nn.Linear(2, 2), 128)
+    with pytest.raises(NotImplementedError):
+        easykv_amd.set_dynamicntk_rope_length(object(), 128)
