@@ -77,9 +77,9 @@ class BudgetedKVCache:
         self.bank = KVBank(n_layers, n_q_heads, n_kv_heads, head_dim, cap, device=device)
         self.plan = StepPlan(policy="full", phase="prefill", accumulate=False)
         self.streaming = streaming
+        self.positions = None    # true position ids of the forward in flight (set by the driver)
+        self.unrotate = None     # HF seam + streaming: (cos, sin) fp32 [>= max position, D] to take the model's RoPE off q/k
         if streaming:
-            if getattr(self, "_hf", False):
-                raise NotImplementedError("streaming=True needs un-rotated keys; the HF adapter hands over rotated ones")
             cos, sin = rope if rope is not None else rope_tables(cap, head_dim)
             self.bank.set_rope(cos, sin)
         self.record = record
@@ -93,9 +93,10 @@ class BudgetedKVCache:
     def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
         return key_states, value_states
 
-    def begin_forward(self, plan: StepPlan):
+    def begin_forward(self, plan: StepPlan, positions=None):
         BudgetedKVCache.current = self
         self.plan = plan
+        self.positions = positions
         self._cur = [] if (self.record and plan.evict) else None
         if self._cur is not None:
             self.evictions.append(self._cur)
@@ -184,14 +185,25 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
         else:
             kv_mode = "encoding_decoding"
 
+    # HF seam + streaming: the stock attention module hands over q/k already rotated by the TRUE positions, while the
+    # streaming variant caches un-rotated keys and rotates by slot index on every read (llama_patch.py:310-327).  The
+    # model's own rotary module supplies both the tables for the read-time rotation and the ones to take its rotation off.
+    hf_stream = streaming and getattr(self.config, "_attn_implementation", None) == "easykv_amd"
+
     def new_cache(cap):
-        return BudgetedKVCache(n_layers, hq, h, d, cap + 8, dev, streaming=streaming, record=record)
+        hf_rope = None
+        if hf_stream:     # tables cover every slot index (< cap) and every true position (< length + max_new_tokens)
+            from . import hf
+            hf_rope = hf.rope_tables_from_model(self, max(cap + 8, length + max_new_tokens + 1) + 64, d, dev)
+        cache = BudgetedKVCache(n_layers, hq, h, d, cap + 8, dev, streaming=streaming, record=record, rope=hf_rope)
+        cache.unrotate = hf_rope
+        return cache
 
     def forward(cache, ids, positions, plan):
         plan.streaming = streaming
-        cache.begin_forward(plan)
-        return self(input_ids=ids, past_key_values=cache,
-                    position_ids=torch.as_tensor(positions, dtype=torch.long, device=dev).view(1, -1), use_cache=True)
+        pos = torch.as_tensor(positions, dtype=torch.long, device=dev)
+        cache.begin_forward(plan, pos)
+        return self(input_ids=ids, past_key_values=cache, position_ids=pos.view(1, -1), use_cache=True)
 
     def sample(logits_last):
         prob, raw = logits_adapter(logits_last.float(), temperature, top_p)

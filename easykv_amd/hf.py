@@ -28,8 +28,34 @@ def _easykv_attention(module, query, key, value, attention_mask=None, dropout=0.
     d = query.shape[-1]
     if scaling is not None and abs(scaling * (d ** 0.5) - 1.0) > 1e-3:
         raise ValueError("easykv_amd attention supports the standard 1/sqrt(head_dim) scaling only")
+    if cache.streaming:
+        # streaming=True (llama_patch.py:310-327) caches UN-rotated keys; the stock module has already applied RoPE at the
+        # true positions, so take it off again (rotation by -theta: x = x'*cos - rotate_half(x')*sin, fp32)
+        if cache.unrotate is None or cache.positions is None:
+            raise RuntimeError("streaming=True through the HF seam needs easykv_generate() to supply the rotary tables")
+        cos, sin = (t[cache.positions].to(torch.float32) for t in cache.unrotate)      # [n, D]
+        query, key = _unrotate(query, cos, sin), _unrotate(key, cos, sin)
     out = cache.attend(module.layer_idx, query, key, value)        # [1, Hq, n, D] fp16
     return out.transpose(1, 2).to(query.dtype), None
+
+
+def _unrotate(x, cos, sin):
+    xf = x.to(torch.float32)
+    half = xf.shape[-1] // 2
+    rot = torch.cat((-xf[..., half:], xf[..., :half]), dim=-1)      # rotate_half (llama_patch.py:13-17)
+    return (xf * cos - rot * sin).to(x.dtype)
+
+
+def rope_tables_from_model(model, n_pos, head_dim, device):
+    """fp32 (cos, sin) ``[n_pos, head_dim]`` from the model's own rotary module (so rope_theta, DynamicNTK / linear
+    scaling and attention scaling are the model's), for the RoPE-on-read variant."""
+    for sub in model.modules():
+        if hasattr(sub, "inv_freq") and hasattr(sub, "rope_type"):
+            x = torch.zeros(1, 1, head_dim, dtype=torch.float32, device=device)
+            with torch.no_grad():
+                cos, sin = sub(x, torch.arange(n_pos, device=device).view(1, -1))
+            return cos[0].to(torch.float32).contiguous(), sin[0].to(torch.float32).contiguous()
+    raise ValueError("no rotary embedding module found in this model")
 
 
 def register():

@@ -71,3 +71,29 @@ def test_eviction_modes_run_on_a_real_hf_model(mode, cfg):
     else:
         _, idx, _ = easykv_amd.geometry("auto", 120, 48, 8)
         assert cache.get_seq_length() == idx
+
+
+def test_streaming_through_the_hf_seam():
+    """streaming=True on a HF model: the adapter takes the module's RoPE off q/k and the kernel rotates by slot index on
+    every read.  With nothing evicted the slot index IS the true position, so the run must reproduce the non-streaming
+    greedy tokens; with eviction it must run and keep the budget."""
+    import easykv_amd
+    from easykv_amd import hf
+    model = hf.patch_model(_tiny(2))
+    easykv_amd.enable_fixed_kv(model, _Tok(), mode="decoding", stride=1)
+    ids = torch.randint(0, 97, (1, 40), device="cuda")
+    base = dict(temperature=1e-6, kv_policy="full", budget=200, max_new_tokens=8, eos_token_ids=[-1])
+    with contextlib.redirect_stdout(io.StringIO()):
+        plain = model.easykv_generate(input_ids=ids, generation_config=dict(base))
+        stream = model.easykv_generate(input_ids=ids, generation_config=dict(base, streaming=True))
+    assert plain == stream
+    with contextlib.redirect_stdout(io.StringIO()):
+        out, cache = model.easykv_generate(input_ids=ids, generation_config=dict(base, streaming=True, kv_policy="roco", budget=32, max_new_tokens=48),
+                                           return_cache=True)
+    assert len(out.split()) == 48 and cache.get_seq_length() == 40 + 32
+    # prefill-side streaming (ppl mode, strided chunks with RoPE-on-read)
+    easykv_amd.enable_fixed_kv(model, _Tok(), mode="encoding", stride=8)
+    ids2 = torch.randint(0, 97, (1, 160), device="cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        ppl = model.easykv_ppl(input_ids=ids2, generation_config=dict(budget=0.5, kv_policy="roco", streaming=True))
+    assert ppl > 1.0 and ppl == ppl
