@@ -13,7 +13,8 @@ path.  The metric is BASELINE.json's: decode tokens/s (path only) + HBM GB/s of 
 N > 1 is launched by torch.distributed.run, one rank per GPU.  Layer blocks are independent
 units (eviction state is per (layer, head)), so every rank owns a 32-layer block and runs the
 same step with no data-path collective (weak scaling); the pipeline hand-off of the north star
-(one [1, hidden] fp16 activation per stage boundary) is issued as an RCCL ring send/recv per step.
+(one [1, hidden] fp16 activation per stage boundary) is issued as an RCCL ring send/recv per step, posted
+after the step's kernels and waited for at the next step (stages of a pipeline work on different tokens).
 The rank-0 line also carries `roofline` (dominant kernel, HIP events) and `cpu_baseline` (the
 oracle timed on the host cores of the same box, bounded sample).
 """
@@ -197,6 +198,7 @@ def main():
     hidden = torch.zeros(1, Hq * D, dtype=torch.float16, device=dev)
     hidden_in = torch.zeros_like(hidden)
 
+    pending = []      # requests of the hand-off still in flight (world > 1)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     n_split, fused = bank.step_plan(plan, 1, 0, min(lpl, L))
     if args.split_kernels:
@@ -227,8 +229,9 @@ def main():
                 bank.attend(*a, overlap_scorer=args.overlap_scorer, **kw)
         if args.overlap_scorer and args.graph:
             bank.join()        # a captured step must end with every forked stream joined
-        if world > 1 and not args.no_handoff:   # pipeline hand-off of the stage output (north star)
-            DS.ring_handoff(hidden, hidden_in, shard)
+        if world > 1 and not args.no_handoff and not args.graph:   # pipeline hand-off of the stage output (north star):
+            # posted after this step's kernels, waited for at the next step, so the 8 KB transfer overlaps the next launch
+            pending[:] = DS.ring_handoff_async(hidden, hidden_in, shard, pending)
 
     for i in range(args.warmup):
         step(i)
@@ -252,6 +255,9 @@ def main():
             graph.replay()
         else:
             step(args.warmup + i, i)
+    for req in pending:       # the last hand-off belongs to the timed region
+        req.wait()
+    pending.clear()
     DS.barrier(dev)
     elapsed = DS.max_over_ranks(time.perf_counter() - t0, dev)
     if graph is not None:   # per-kernel durations: a short eager pass with HIP events
@@ -282,7 +288,7 @@ def main():
         cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={L} Hq={Hq} H={H} D={D} budget={budget} "
                            f"T={T} kv_policy={args.policy} (Llama2-7B shape, budget=50% of S=4096)",
                "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [shard.begin, shard.end], "n_split": n_split, "fused": fused, "hipgraph": bool(args.graph), "overlap_scorer": bool(args.overlap_scorer),
-               "handoff": (world > 1 and not args.no_handoff)}
+               "handoff": (world > 1 and not args.no_handoff and not args.graph)}
         line = {
             "metric": "decode_tokens_per_sec", "value": world * args.steps / elapsed, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -69,6 +69,20 @@ def ring_handoff(send: torch.Tensor, recv: torch.Tensor, shard: LayerShard):
         req.wait()
 
 
+def ring_handoff_async(send: torch.Tensor, recv: torch.Tensor, shard: LayerShard, pending=None):
+    """Pipelined hand-off: first make the current stream wait for the PREVIOUS step's transfer (``pending``), then post
+    this step's send/recv and return its requests without waiting — the transfer runs on the communicator's stream while
+    the next step's kernels execute, as in a pipeline whose stages work on different tokens.  ``send``/``recv`` may be
+    reused every step: the previous transfer has been waited for before the new one is posted."""
+    for req in pending or ():
+        req.wait()
+    if shard.world == 1:
+        recv.copy_(send)
+        return []
+    ops = [dist.P2POp(dist.isend, send, shard.next_rank), dist.P2POp(dist.irecv, recv, shard.prev_rank)]
+    return list(dist.batch_isend_irecv(ops))
+
+
 def barrier(device=None):
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)

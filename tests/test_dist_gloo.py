@@ -73,3 +73,44 @@ def test_two_rank_pipeline_handoff():
     assert torch.allclose(h1, ref)            # the last stage holds the full-depth result
     assert torch.allclose(recv0, h1)          # ...and the ring returns it to stage 0 (next token's input)
     assert t0 == t1 == 2.0                    # max over ranks
+
+
+def _worker_async(rank, world, port, steps, out_q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from easykv_amd import dist as D
+    r, _, w = D.init("gloo")
+    shard = D.LayerShard(r, w, 4 * w)
+    send, recv = torch.zeros(1, 8), torch.zeros(1, 8)
+    got, pending = [], []
+    for i in range(steps):
+        # what bench.py does: this step's "kernels", then wait for the previous transfer and post this step's
+        if i > 0:
+            for req in pending:
+                req.wait()
+            got.append(recv.clone())                 # the value posted by the previous rank at step i-1
+            pending = []
+        send.fill_(float(100 * r + i))
+        pending = D.ring_handoff_async(send, recv, shard, pending)
+    for req in pending:
+        req.wait()
+    got.append(recv.clone())
+    out_q.put((r, [float(g[0, 0]) for g in got]))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_pipelined_async_handoff():
+    """bench.py's overlapped hand-off: the transfer of step i is waited for at step i+1; every step's value arrives, in order."""
+    world, steps = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == [100.0 + i for i in range(steps)]     # rank 0 receives rank 1's values
+    assert res[1] == [0.0 + i for i in range(steps)]
