@@ -119,6 +119,11 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   // key-range splits: aim for >= 1024 workgroups, never fewer than 256 positions per split
   const int wg_unit = st->q_len == 1 ? 128 : 64;
   int n_split = st->n_split;
+  w.fused_nw = ekv_decode_fused_nw(st->layer_count * bank->n_kv_heads);
+  if (n_split <= 0 && st->q_len == 1 && st->layer_count * bank->n_kv_heads >= 256 && w.fused_nw == 8 &&
+      ekv_decode_fused_supported(bank->head_dim, rep, T, w.t_pad, st->n_evict, bank->cap, 8)) {
+    n_split = 1;   // >= 1 head per CU: one 8-wave workgroup per head beats key-range splits + a second kernel (GQA shapes)
+  }
   if (n_split <= 0) {
     const int wgs = st->layer_count * bank->n_kv_heads * w.n_qblocks;
     // decode: >= 1024 workgroups (4 per CU, one round).  chunk kernels hold 3 (QPW=1) or 2 workgroups per CU: a grid of
@@ -185,7 +190,7 @@ int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, in
   const EkvWs ws = ekv_plan_workspace(bank, st, nullptr);
   *n_split = ws.n_split;
   *fused = (st->q_len == 1 && st->phases == 0 && st->n_split != -1 && ws.n_split == 1 &&
-            ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, st->n_evict, bank->cap))
+            ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, st->n_evict, bank->cap, ws.fused_nw))
                ? 1 : 0;
   return EKV_OK;
 }
@@ -308,8 +313,8 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
 
   // whole decode step in one launch when no head has to be split
   if (n == 1 && st->phases == 0 && ws.n_split == 1 &&
-      ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, st->n_evict, bank->cap)) {
-    return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+      ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, st->n_evict, bank->cap, ws.fused_nw)) {
+    return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, ws.fused_nw, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
 
   // phases: 0 = whole step; else a bit mask: 1 attention kernel, 2 scorer (fold + score), 4 fold only, 8 scorer

@@ -3,23 +3,23 @@
 #include "ekv_kernels.h"
 
 hipError_t ekv_launch_attn_decode_d32_plain(const EkvAttnArgs&, int, int, hipStream_t);
-hipError_t ekv_launch_decode_fused_d32_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, hipStream_t);
-size_t ekv_fused_lds_d32_plain(int, int);
+hipError_t ekv_launch_decode_fused_d32_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
+size_t ekv_fused_lds_d32_plain(int, int, int);
 hipError_t ekv_launch_attn_decode_d32_rope(const EkvAttnArgs&, int, int, hipStream_t);
-hipError_t ekv_launch_decode_fused_d32_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, hipStream_t);
-size_t ekv_fused_lds_d32_rope(int, int);
+hipError_t ekv_launch_decode_fused_d32_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
+size_t ekv_fused_lds_d32_rope(int, int, int);
 hipError_t ekv_launch_attn_decode_d64_plain(const EkvAttnArgs&, int, int, hipStream_t);
-hipError_t ekv_launch_decode_fused_d64_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, hipStream_t);
-size_t ekv_fused_lds_d64_plain(int, int);
+hipError_t ekv_launch_decode_fused_d64_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
+size_t ekv_fused_lds_d64_plain(int, int, int);
 hipError_t ekv_launch_attn_decode_d64_rope(const EkvAttnArgs&, int, int, hipStream_t);
-hipError_t ekv_launch_decode_fused_d64_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, hipStream_t);
-size_t ekv_fused_lds_d64_rope(int, int);
+hipError_t ekv_launch_decode_fused_d64_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
+size_t ekv_fused_lds_d64_rope(int, int, int);
 hipError_t ekv_launch_attn_decode_d128_plain(const EkvAttnArgs&, int, int, hipStream_t);
-hipError_t ekv_launch_decode_fused_d128_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, hipStream_t);
-size_t ekv_fused_lds_d128_plain(int, int);
+hipError_t ekv_launch_decode_fused_d128_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
+size_t ekv_fused_lds_d128_plain(int, int, int);
 hipError_t ekv_launch_attn_decode_d128_rope(const EkvAttnArgs&, int, int, hipStream_t);
-hipError_t ekv_launch_decode_fused_d128_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, hipStream_t);
-size_t ekv_fused_lds_d128_rope(int, int);
+hipError_t ekv_launch_decode_fused_d128_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
+size_t ekv_fused_lds_d128_rope(int, int, int);
 
 bool ekv_attn_decode_supported(int head_dim, int rep) {
   return (head_dim == 32 || head_dim == 64 || head_dim == 128) && (rep == 1 || rep == 2 || rep == 4 || rep == 8);
@@ -40,24 +40,25 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 }
 
 // The whole decode step in one launch: possible when a head is not split, at most one victim, and the row fits.
-bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap) {
+// nw = 4: up to four workgroups per CU (LDS <= 64 KB keeps >= 2); nw = 8: one or two workgroups per CU.
+int ekv_decode_fused_nw(int n_heads_in_launch) { return (n_heads_in_launch >= 256 && n_heads_in_launch <= 512) ? 8 : 4; }
+
+bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap, int nw) {
   // (the slot map and the score rows are fetched 16 bytes at a time: rows must be 16-byte aligned)
   if (!ekv_attn_decode_supported(head_dim, rep) || n_evict > 1 || n_slots > 256 * 24 || (cap & 3) != 0 || cap < 16) return false;
-  const bool rope = false;
   size_t lds = 1 << 30;
   switch (head_dim) {
-    case 32: lds = ekv_fused_lds_d32_plain(rep, t_pad); break;
-    case 64: lds = ekv_fused_lds_d64_plain(rep, t_pad); break;
-    case 128: lds = ekv_fused_lds_d128_plain(rep, t_pad); break;
+    case 32: lds = ekv_fused_lds_d32_plain(rep, t_pad, nw); break;
+    case 64: lds = ekv_fused_lds_d64_plain(rep, t_pad, nw); break;
+    case 128: lds = ekv_fused_lds_d128_plain(rep, t_pad, nw); break;
   }
-  (void)rope;
-  return lds <= 64 * 1024;
+  return lds <= (nw == 8 ? 150 : 64) * 1024;
 }
 
-hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count,
+hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, int nw,
                                    hipStream_t s) {
   const int rep = a.n_q_heads / a.n_kv_heads;
   const bool rope = a.rope_cos != nullptr;
-  EKV_DISPATCH(ekv_launch_decode_fused_d, a, sc, rep, layer_count, s)
+  EKV_DISPATCH(ekv_launch_decode_fused_d, a, sc, rep, layer_count, nw, s)
   return hipErrorInvalidValue;
 }

@@ -14,6 +14,7 @@ struct EkvWs {
   float* stats;     // two-pass chunk steps (see EkvAttnArgs)
   float* colsum;
   int32_t two_pass, n_col_parts;
+  int32_t fused_nw;     // waves per workgroup the fused decode kernel would use for this launch (4 or 8)
   __half* q_rot;    // rope_on_read chunk steps: [2][layer_count][Hq][q_len][D] rotated queries, fp16 hi then lo
   int32_t t_pad, n_split, rows_per_split;
   int32_t n_partials;   // partials per query row the scorer folds (chunk kernels emit 2 per split)
@@ -71,8 +72,9 @@ bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumu
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 bool ekv_attn_decode_supported(int head_dim, int rep);
-bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap);
-hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, hipStream_t s);
+int ekv_decode_fused_nw(int n_heads_in_launch);
+bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap, int nw);
+hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, int nw, hipStream_t s);
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len);
 void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw);
 size_t ekv_score_lds_bytes(const EkvScoreArgs& a);

@@ -73,3 +73,53 @@ def test_decode_matches_reference_golden(name, n_split):
     k_ord, _ = bank.ordered_kv()
     kept = int(g["meta"]["printed"].split("(")[1].split("/")[0])     # the reference's own printed budget line
     assert k_ord.shape[2] == g["meta"]["length"] + kept
+
+
+@pytest.mark.parametrize("hq,h,d,policy,stream", [(8, 8, 64, "roco", False), (16, 4, 128, "roco", False), (16, 2, 32, "h2o_head", True),
+                                                  (8, 8, 128, "tova", False), (32, 4, 64, "roco", True)])
+def test_eight_wave_fused_kernel_for_launches_with_one_or_two_heads_per_cu(hq, h, d, policy, stream):
+    """256..512 KV heads in one launch (e.g. Mistral: 8 KV heads x 32 layers) run the fused decode step with 8-wave
+    workgroups, one per head.  Same trajectory as the split path (attention kernel + decode scorer), layer by layer
+    against the oracle for the first layers."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    L = 256 // h
+    budget, steps, P = 150, 12, 5
+    g = torch.Generator().manual_seed(hq * 7 + d)
+    T0 = P + budget
+    k0, v0 = torch.randn(L, h, T0, d, generator=g).half(), torch.randn(L, h, T0, d, generator=g).half()
+    warm = torch.rand(L, h, budget + 1, generator=g) * 1e-3
+    banks = {}
+    cos = sin = None
+    if stream:
+        cos, sin = O.rope_tables(T0 + 16, d)
+    for name in ("fused", "split"):
+        b = KVBank(L, hq, h, d, cap=T0 + 1)
+        if stream:
+            b.set_rope(cos, sin)
+        b.load_rows(k0.cuda(), v0.cuda())
+        b.state_init(budget + 1, 0)
+        b.score_sum[:, :, :budget + 1] += warm.cuda()
+        b.score_sq[:, :, :budget + 1] += (warm ** 2).cuda()
+        banks[name] = b
+    kw = dict(policy=policy, phase="decode", evict=True, score_off=P, budget=budget, streaming=stream)
+    assert banks["fused"].step_plan(StepPlan(**kw), 1) == (1, True)          # auto plan: unsplit and fused
+    n_check = 2
+    sts = []
+    for l in range(n_check):
+        st = O.LayerState(k=k0[l:l + 1].float(), v=v0[l:l + 1].float())
+        st.s, st.q, st.c = O.init_state_decoding((h,), budget)
+        st.s += warm[l]
+        st.q += warm[l] ** 2
+        sts.append(st)
+    for i in range(steps):
+        q, k, v = (torch.randn(L, n, 1, d, generator=g).half() for n in (hq, h, h))
+        o_f, i_f = banks["fused"].attend(StepPlan(**kw), q.cuda(), k.cuda(), v.cuda())
+        o_s, i_s = banks["split"].attend(StepPlan(n_split=2, **kw), q.cuda(), k.cuda(), v.cuda())
+        assert torch.equal(i_f, i_s), i
+        assert torch.allclose(o_f.float(), o_s.float(), atol=1e-3, rtol=5e-4)
+        for l in range(n_check):
+            o_ref, ids_ref = O.layer_step(sts[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw), cos, sin)
+            assert torch.allclose(o_f[l].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4)
+    assert torch.equal(banks["fused"].slot_of_pos, banks["split"].slot_of_pos)
+    assert torch.allclose(banks["fused"].score_sum, banks["split"].score_sum, rtol=1e-6, atol=0)
