@@ -40,7 +40,7 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 }
 
 // The whole decode step in one launch: possible when a head is not split, at most one victim, and the row fits.
-// nw = 4: up to four workgroups per CU (LDS <= 64 KB keeps >= 2); nw = 8: one or two workgroups per CU.
+// nw = 4: up to four workgroups per CU (LDS <= 80 KB keeps >= 2); nw = 8: one or two workgroups per CU.
 int ekv_decode_fused_nw(int n_heads_in_launch) { return (n_heads_in_launch >= 256 && n_heads_in_launch <= 512) ? 8 : 4; }
 
 bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap, int nw) {
@@ -52,7 +52,7 @@ bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, i
     case 64: lds = ekv_fused_lds_d64_plain(rep, t_pad, nw); break;
     case 128: lds = ekv_fused_lds_d128_plain(rep, t_pad, nw); break;
   }
-  return lds <= (nw == 8 ? 150 : 64) * 1024;
+  return lds <= (nw == 8 ? 150 : 80) * 1024;   // 80 KB still leaves two 4-wave workgroups per CU
 }
 
 hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, int nw,
