@@ -155,6 +155,9 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   off += ekv_align(rowsq * w.n_partials * (bank->head_dim + 2) * 4, 256);
   w.tova_row = reinterpret_cast<float*>(p + off);
   off += ekv_align((size_t)st->layer_count * w.t_pad * 4, 256);
+  // unsplit chunk steps fold the two key halves inside the attention kernel unless the scorer needs the per-split softmax
+  // statistics (one-pass scored steps take the row statistics from the partials)
+  w.fold_in_kernel = (st->q_len > 1 && w.n_split == 1 && (w.two_pass || !(scored && st->accumulate))) ? 1 : 0;
   w.q_rot = nullptr;
   if (st->rope_on_read && st->q_len > 1) {
     w.q_rot = reinterpret_cast<__half*>(p + off);
@@ -259,6 +262,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.rope_sin = st->rope_on_read ? rope_sin : nullptr;
   aa.q_rot_hi = ws.q_rot;
   aa.q_rot_lo = ws.q_rot ? ws.q_rot + (size_t)st->layer_count * bank->n_q_heads * n * bank->head_dim : nullptr;
+  aa.out_direct = ws.fold_in_kernel ? static_cast<__half*>(out) : nullptr;
   aa.stats = ws.stats;
   aa.colsum = ws.colsum;
   aa.n_col_parts = ws.n_col_parts;
@@ -335,11 +339,11 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
 
   if ((ph & 4) || (!scored && st->n_evict == 0 && !(ph & 8))) {
     // nothing to score and nothing to evict ('full', or any unknown policy string): the step is the partial fold only,
-    // whatever the cache length
-    if (ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+    // whatever the cache length (and not even that when the attention kernel has already written the output)
+    if (!ws.fold_in_kernel && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
     if (!(ph & 8)) return EKV_OK;
   }
-  sa.skip_fold = (ph & 8) ? 1 : 0;
+  sa.skip_fold = ((ph & 8) || ws.fold_in_kernel) ? 1 : 0;
   if (ekv_decode_score_supported(sa))   // decode steps: the fast scorer (same tail as the fused kernel)
     return ekv_launch_decode_score(sa, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   if (ekv_score_lds_bytes(sa) > 160 * 1024) return EKV_E_UNSUPPORTED;
