@@ -16,12 +16,19 @@ if STREAM:
     from easykv_amd.api import rope_tables
     bank.set_rope(*rope_tables(idx+stride+8, D))
 def rnd(h,n): return torch.randn(L,h,n,D,generator=g,device=dev).half()
-# dense prefix, layer blocks of 8 to bound the workspace
-torch.cuda.synchronize(); t0=time.perf_counter()
-for l0 in range(0,L,8):
-    q,k,v = (x[l0:l0+8].contiguous() for x in (rnd(Hq,r_idx),rnd(H,r_idx),rnd(H,r_idx)))
-    bank.attend(StepPlan(policy='full',phase='prefill',accumulate=False,streaming=STREAM), q,k,v, layer_begin=l0)
-torch.cuda.synchronize(); t_prefix=time.perf_counter()-t0
+# dense prefix, layer blocks of 8 to bound the workspace; inputs generated up front, first pass = warm-up on a scratch bank
+qp = [tuple(rnd(h, r_idx)[:8].contiguous() for h in (Hq, H, H)) for _ in range(L // 8)]
+for timed in (False, True):
+    b = bank if timed else KVBank(L,Hq,H,D,cap=idx+stride)
+    if STREAM and not timed:
+        from easykv_amd.api import rope_tables
+        b.set_rope(*rope_tables(idx+stride+8, D))
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    for i, l0 in enumerate(range(0,L,8)):
+        q,k,v = qp[i]
+        b.attend(StepPlan(policy='full',phase='prefill',accumulate=False,streaming=STREAM), q,k,v, layer_begin=l0)
+    torch.cuda.synchronize(); t_prefix=time.perf_counter()-t0
+    del b
 bank.state_init(idx+stride,2,stride)
 n_chunks=(S-r_idx)//stride
 qs=[rnd(Hq,stride) for _ in range(4)]; ks=[rnd(H,stride) for _ in range(4)]; vs=[rnd(H,stride) for _ in range(4)]
