@@ -155,9 +155,14 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   off += ekv_align(rowsq * w.n_partials * (bank->head_dim + 2) * 4, 256);
   w.tova_row = reinterpret_cast<float*>(p + off);
   off += ekv_align((size_t)st->layer_count * w.t_pad * 4, 256);
-  // unsplit chunk steps fold the two key halves inside the attention kernel unless the scorer needs the per-split softmax
-  // statistics (one-pass scored steps take the row statistics from the partials)
-  w.fold_in_kernel = (st->q_len > 1 && w.n_split == 1 && (w.two_pass || !(scored && st->accumulate))) ? 1 : 0;
+  // unsplit chunk steps fold the two key halves inside the attention kernel (one-pass scored steps also get the final row
+  // statistics from it)
+  w.fold_in_kernel = (st->q_len > 1 && w.n_split == 1) ? 1 : 0;
+  w.row_stats = nullptr;
+  if (w.fold_in_kernel && !w.two_pass && scored && st->accumulate) {   // one-pass scored: the scorer still needs (M, L) per row
+    w.row_stats = reinterpret_cast<float*>(p + off);
+    off += ekv_align(rowsq * 2 * 4, 256);
+  }
   w.q_rot = nullptr;
   if (st->rope_on_read && st->q_len > 1) {
     w.q_rot = reinterpret_cast<__half*>(p + off);
@@ -263,6 +268,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.q_rot_hi = ws.q_rot;
   aa.q_rot_lo = ws.q_rot ? ws.q_rot + (size_t)st->layer_count * bank->n_q_heads * n * bank->head_dim : nullptr;
   aa.out_direct = ws.fold_in_kernel ? static_cast<__half*>(out) : nullptr;
+  aa.row_stats = ws.row_stats;
   aa.stats = ws.stats;
   aa.colsum = ws.colsum;
   aa.n_col_parts = ws.n_col_parts;
@@ -289,6 +295,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   sa.partials = ws.partials;
   sa.tova_row = ws.tova_row;
   sa.colsum = ws.colsum;
+  sa.row_stats = ws.row_stats;
   sa.n_col_parts = ws.n_col_parts;
   sa.out = static_cast<__half*>(out);
   sa.evict_ids = evict_ids;

@@ -8,16 +8,17 @@ EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 #undef EKV_DECL
 
 // Two-pass scheme (statistics pass + exact pass with in-kernel column sums, see ekv_attn_chunk.inc) for scored chunk
-// steps.  It trades one extra read of K for the rep x n x T logits never touching HBM.  Measured on MI355X (DESIGN.md
-// §8): the one-pass kernel + logits wins while the scorer keeps >= 2 workgroups per CU; once the score rows alone need
-// more than half of the LDS (W > ~4800) the scorer's pass over the logits falls off a cliff and two passes win.
-// tova needs the last query row itself, not column sums, and always stays on the one-pass kernel.
+// steps.  It trades one extra read of K for the rep x n x T logits never touching HBM.  Measured on MI355X,
+// once the one-pass kernel and the scorer's logits sweep were cleaned up the one-pass path wins at every BASELINE shape
+// (C4: 1.89 vs 2.31 ms per step, stride 64: 0.62 vs 0.67, C5 with RoPE-on-read: 1.98 vs 2.59), so `auto` never picks two
+// passes; ekv_step.two_pass = 1 selects them explicitly (kept tested: every golden case runs under both schemes) — the scheme
+// becomes the better one again if the statistics pass is made bandwidth-bound.  tova needs the last query row itself, not
+// column sums, and always uses the one-pass kernel.
 bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, int width, int mode) {
+  (void)width;
   const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // rep query heads share a 16-lane row
   const bool can = q_len > 1 && scored && accumulate && policy != EKV_POLICY_TOVA && rep_ok;
-  if (!can || mode < 0) return false;
-  if (mode > 0) return true;
-  return rep * q_len >= 32 && (size_t)width * 16 > 76 * 1024;
+  return can && mode > 0;
 }
 
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len) {

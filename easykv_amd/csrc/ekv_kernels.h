@@ -14,6 +14,7 @@ struct EkvWs {
   float* stats;     // two-pass chunk steps (see EkvAttnArgs)
   float* colsum;
   int32_t two_pass, n_col_parts;
+  float* row_stats;
   int32_t fold_in_kernel;   // chunk step whose attention kernel writes the final output itself (no partials, no fold)
   int32_t fused_nw;     // waves per workgroup the fused decode kernel would use for this launch (4 or 8)
   __half* q_rot;    // rope_on_read chunk steps: [2][layer_count][Hq][q_len][D] rotated queries, fp16 hi then lo
@@ -38,6 +39,7 @@ struct EkvAttnArgs {
   const float* rope_sin;
   __half* q_rot_hi;  // chunk kernels with rope_on_read: queries rotated by ekv_rope_q_kernel (hi + lo fp16 pair)
   __half* q_rot_lo;
+  float* row_stats;    // with out_direct, one-pass scored steps: [layer_count][Hq][q_len][2] final (max, sum exp) per query row
   __half* out_direct;  // chunk kernels, unsplit heads: fold the two key halves in the kernel and write the fp16 output here
   float* stats;      // two-pass chunk steps: [layer_count][Hq][q_len][2*n_split][2] (max, sum exp) per key-range half split
   float* colsum;     // two-pass chunk steps: [layer_count][H][n_col_parts][2][t_pad] column sums of pbar and pbar^2
@@ -55,6 +57,7 @@ struct EkvScoreArgs {
   const float* logits;
   const float* partials;
   const float* colsum;   // non-null: column sums from the two-pass chunk kernel replace the logits
+  const float* row_stats;   // non-null: final row statistics written by the chunk kernel (its in-kernel fold)
   int32_t n_col_parts;
   float* tova_row;
   __half* out;

@@ -12,8 +12,10 @@ hipError_t ekv_launch_tova_headmean_nt512(const EkvScoreArgs&, int, hipStream_t)
 size_t ekv_score_lds_bytes(const EkvScoreArgs& a) { return ekv_score_lds_bytes_nt512(a); }
 
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s) {
-  return (a.n_kv_heads * layer_count >= 768) ? ekv_launch_score_select_nt256(a, layer_count, s)
-                                             : ekv_launch_score_select_nt512(a, layer_count, s);
+  // 256 threads only while at least three such workgroups fit a CU's LDS; wide score rows (C4: W = 5098 -> 82 KB) leave
+  // room for one workgroup per CU, which must then bring 512 threads
+  const bool small_blocks = a.n_kv_heads * layer_count >= 768 && ekv_score_lds_bytes_nt256(a) <= 53 * 1024;
+  return small_blocks ? ekv_launch_score_select_nt256(a, layer_count, s) : ekv_launch_score_select_nt512(a, layer_count, s);
 }
 
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s) {
