@@ -97,6 +97,23 @@ def device_copy_gbs(dev, nbytes=1 << 30, iters=8):
     return 2.0 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def event_overhead_us(dev, reps=32):
+    """What a HIP-event pair adds around ONE kernel launch: events around a one-element kernel (whose own run time is ~2 us).
+    Informational: `roofline.achieved` uses the raw event durations (conservative); the rocprofv3 kernel trace under
+    profiles/ shows the pure kernel duration, which is shorter by about this much."""
+    x = torch.zeros(1, device=dev)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        x.add_(1.0)
+        e1.record()
+        ts.append((e0, e1))
+    torch.cuda.synchronize(dev)
+    v = sorted(a.elapsed_time(b) * 1e3 for a, b in ts[4:])
+    return v[len(v) // 2]
+
+
 def strided_prefill(args, dev, n_chunks=24, warm=4):
     """Secondary figure (never `value`): BASELINE.json configs[1] — the chunk phase of a strided prefill, S=4096, stride 8,
     budget 0.5, kv_policy roco (SURVEY.md §8d Bench-P): the cache oscillates idx <-> idx+stride, every chunk step attends
@@ -153,6 +170,8 @@ def main():
     ap.add_argument("--layers-per-launch", type=int, default=0, help="0 = all layers of the rank in one launch")
     ap.add_argument("--n-split", type=int, default=0, help="key-range splits per head (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-events", action="store_true", help="fused path: bracket every launch with its own HIP event pair instead "
+                    "of one pair around the timed region (adds ~6 us of marker latency per step)")
     ap.add_argument("--no-prefill", action="store_true", help="skip the secondary strided-prefill (configs[1]) figure")
     ap.add_argument("--no-handoff", action="store_true")
     ap.add_argument("--split-kernels", action="store_true", help="force the two-kernel path (attention + score/select)")
@@ -247,14 +266,22 @@ def main():
             step(0)
         torch.cuda.synchronize()
 
+    # Kernel timing for the roofline.  Fused path (one kernel per step, launches back to back): ONE HIP-event pair around the
+    # timed region, duration per launch = region / steps (an upper bound: it contains any gap between launches).  An event
+    # pair around every launch costs ~6 us of marker latency per step, lowers `value` and still over-states the kernel time.
+    # Split path (two kernels per step): per-step events, needed for the per-kernel breakdown.
+    per_step_events = args.step_events or not fused or lpl != L or bool(args.graph)
     DS.barrier(dev)
+    region = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
     t0 = time.perf_counter()
+    region[0].record()
     for i in range(args.steps):
         if graph is not None:
             sq.copy_(qs_src[args.warmup + i]); sk.copy_(ks_src[args.warmup + i]); sv.copy_(vs_src[args.warmup + i])
             graph.replay()
         else:
-            step(args.warmup + i, i)
+            step(args.warmup + i, i if per_step_events else None)
+    region[1].record()
     for req in pending:       # the last hand-off belongs to the timed region
         req.wait()
     pending.clear()
@@ -284,7 +311,8 @@ def main():
         n_state = {"roco": 3, "h2o_head": 1, "tova": 1}.get(args.policy, 0)
         b = algorithmic_bytes(H, Hq, D, T, 1, n_state)
         lc0 = min(lpl, L)
-        t_attn = 1.0 if args.overlap_scorer else sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3
+        t_region = region[0].elapsed_time(region[1]) / args.steps * 1e-3
+        t_attn = t_region if not per_step_events else (1.0 if args.overlap_scorer else sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3)
         cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={L} Hq={Hq} H={H} D={D} budget={budget} "
                            f"T={T} kv_policy={args.policy} (Llama2-7B shape, budget=50% of S=4096)",
                "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [shard.begin, shard.end], "n_split": n_split, "fused": fused, "hipgraph": bool(args.graph), "overlap_scorer": bool(args.overlap_scorer),
@@ -315,6 +343,9 @@ def main():
             copy = device_copy_gbs(dev)
             line["roofline"]["device_copy_gbs"] = copy      # measured read+write copy bandwidth of this GPU
             line["roofline"]["frac_of_device_copy"] = gbs / copy
+            line["roofline"]["event_pair_around_1elem_kernel_us"] = event_overhead_us(dev)
+            line["roofline"]["timing"] = ("HIP event pair around every launch" if per_step_events else
+                                          "one HIP event pair around the timed region / steps (launches are back to back)")
         elif args.overlap_scorer:
             line["roofline"] = None     # kernels of different layers overlap: per-kernel event timing is not meaningful here
         else:
