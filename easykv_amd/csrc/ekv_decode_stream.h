@@ -36,7 +36,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   int t1 = t1_in;
 
   uint4 qv[REP];
-  float qf[REP][8], qr[REP][8];  // ROPE: rotated query and its rotate_half partner, fp32
+  float qf[REP][8];  // ROPE: rotated query q' (fp32)
 #pragma unroll
   for (int r = 0; r < REP; ++r) {
     const __half* qp = a.q + ((size_t)ll * a.n_q_heads + h * REP + r) * D;
@@ -53,14 +53,28 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         const float x = __half2float(qp[d]), y = __half2float(qp[dp]);
         qf[r][i] = x * c[d] + (d < half_d ? -y : y) * s[d];
       }
-      // partner values q'[d +- D/2] live in lane sub +- LPR/2 of the same row group
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float other = __shfl_xor(qf[r][i], LPR / 2, 64);
-        qr[r][i] = (sub < LPR / 2) ? other : -other;
-      }
     }
   }
+
+  // RoPE-on-read: keys are cached un-rotated and rotated by their SLOT index j at read time (llama_patch.py:312, :327):
+  // k'[d] = k[d]*cos[j][d] + rotate_half(k)[d]*sin[j][d]; the partner k[d +- D/2] sits in lane sub ^ LPR/2 of the row's lane
+  // group.  The row is rotated ONCE (fp32) and then dotted with each of the REP rotated queries.
+  auto rope_key = [&](const uint4& kv, int j, float (&kp)[8]) {
+    uint4 other;
+    other.x = __shfl_xor(kv.x, LPR / 2, 64);
+    other.y = __shfl_xor(kv.y, LPR / 2, 64);
+    other.z = __shfl_xor(kv.z, LPR / 2, 64);
+    other.w = __shfl_xor(kv.w, LPR / 2, 64);
+    const ekv_h8 kh = __builtin_bit_cast(ekv_h8, kv), oh = __builtin_bit_cast(ekv_h8, other);
+    const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)j * D + sub * 8);
+    const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)j * D + sub * 8);
+    const float4 c0 = c4[0], c1 = c4[1], s0 = s4[0], s1 = s4[1];
+    const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sgn = (sub < LPR / 2) ? -1.f : 1.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kp[i] = fmaf((float)kh[i], cc[i], sgn * (float)oh[i] * ss[i]);
+  };
 
   const __half* k_new_row = a.k_new + ((size_t)ll * a.n_kv_heads + h) * D;
   const __half* v_new_row = a.v_new + ((size_t)ll * a.n_kv_heads + h) * D;
@@ -86,19 +100,15 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   if (has_new && wave == 0 && grp == 0) {
     const uint4 kn = reinterpret_cast<const uint4*>(k_new_row)[sub];
     const uint4 vn = reinterpret_cast<const uint4*>(v_new_row)[sub];
+    float kpn[8];
+    if (ROPE) rope_key(kn, t_new, kpn);
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
       float acc;
       if (ROPE) {
-        const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)t_new * D + sub * 8);
-        const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)t_new * D + sub * 8);
-        const float4 c0 = c4[0], c1 = c4[1], s0 = s4[0], s1 = s4[1];
-        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const ekv_h8 kh = __builtin_bit_cast(ekv_h8, kn);
         acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc = fmaf((float)kh[i], fmaf(qr[r][i], ss[i], qf[r][i] * cc[i]), acc);
+        for (int i = 0; i < 8; ++i) acc = fmaf(kpn[i], qf[r][i], acc);
       } else {
         acc = ekv_dot8(qv[r], kn, 0.f);
       }
@@ -141,29 +151,34 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
       kr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(kp) + sub));
       vr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(vp) + sub));
     }
+    float sall[ROPE ? REP : 1][kU];   // ROPE: every row is rotated once, then dotted with all REP queries
+    if (ROPE) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        float kp[8];
+        rope_key(kr[u], min(j0 + u, t1 - 1), kp);
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+          float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc = fmaf(kp[i], qf[r][i], acc);
+          acc = ekv_group_sum<LPR>(acc);
+          sall[r][u] = (j0 + u < t1) ? acc / a.sm_div : EKV_NEG_INF;
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
       float s[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        float acc;
         if (ROPE) {
-          // q'.(k*cos_j + rotate_half(k)*sin_j) == k.(q'*cos_j + qr*sin_j): rotate the query side per key
-          const int j = min(j0 + u, t1 - 1);
-          const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)j * D + sub * 8);
-          const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)j * D + sub * 8);
-          const float4 c0 = c4[0], c1 = c4[1], s0 = s4[0], s1 = s4[1];
-          const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-          const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-          const ekv_h8 kh = __builtin_bit_cast(ekv_h8, kr[u]);
-          acc = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc = fmaf((float)kh[i], fmaf(qr[r][i], ss[i], qf[r][i] * cc[i]), acc);
+          s[u] = sall[r][u];
         } else {
-          acc = ekv_dot8(qv[r], kr[u], 0.f);
+          float acc = ekv_dot8(qv[r], kr[u], 0.f);
+          acc = ekv_group_sum<LPR>(acc);
+          s[u] = (j0 + u < t1) ? acc / a.sm_div : EKV_NEG_INF;
         }
-        acc = ekv_group_sum<LPR>(acc);
-        s[u] = (j0 + u < t1) ? acc / a.sm_div : EKV_NEG_INF;
       }
       // export the raw logits: lane `sub` of the group owns row j0+sub -> 8 consecutive floats per group
       // (D = 32 has only 4 lanes per row: each lane then owns rows sub and sub + 4)
