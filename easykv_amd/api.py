@@ -171,6 +171,7 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
     eos_token_ids = cfg.get("eos_token_ids", [self.tokenizer.eos_token_id])
     streaming = cfg.get("streaming", False)
     record = cfg.get("_record_evictions", False)      # test hook: keep the evicted ids of every forward
+    use_graph = cfg.get("hipgraph", False)            # extension key: capture the steady-state decode step in a hipGraph
     n_layers, hq, h, d = _dims(self)
     dev = torch.device(self.device)
     length = input_ids.shape[-1]
@@ -209,11 +210,36 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
         prob, raw = logits_adapter(logits_last.float(), temperature, top_p)
         return torch.multinomial(prob, num_samples=1)
 
+    class GraphedStep:
+        """One decode forward of the WHOLE model captured in a hipGraph.  At a fixed budget every decode
+        step that evicts has the same shapes, the same StepPlan and the same cache length before and after, so the host work
+        of a step (HF's per-layer Python, ~0.5 ms per layer) is paid once at capture and a token costs one graph launch.
+        Token id and position live in static device tensors; sampling and the EOS test stay outside the graph."""
+
+        def __init__(self, cache, plan, tok, pos):
+            self.tok = tok.view(1, 1).clone()
+            self.pos = torch.full((1,), pos, dtype=torch.long, device=dev)
+            self.graph = torch.cuda.CUDAGraph()
+            plan.streaming = streaming
+            with torch.cuda.graph(self.graph):      # capture launches nothing: the first replay runs this step
+                cache.begin_forward(plan, self.pos)
+                self.logits = self_model(input_ids=self.tok, past_key_values=cache, position_ids=self.pos.view(1, -1),
+                                         use_cache=True).logits[:, -1, :]
+
+        def __call__(self, tok, pos):
+            self.tok.copy_(tok.view(1, 1))
+            self.pos.fill_(pos)
+            self.graph.replay()
+            return self.logits
+
+    self_model = self
+
     # ---- single-token decode with eviction (decoding mode, and the tail of auto mode) ----------------------
     def decode_loop(cache, logits_last, cur_pos, score_off, budget_d, whole_cache):
         out_ids: List[int] = []
         positions: List[int] = []
         n = 0
+        graphed, prev_sig = None, None
         while n < max_new_tokens:                               # :257 / :670
             tok = sample(logits_last)
             out_ids.append(int(tok[0, 0]))
@@ -233,7 +259,15 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                     e = 0 if policy == "recency" else int(torch.randint(len(positions), (1,)))
                     positions.pop(e)
                     plan.range_start = score_off + e
-            logits_last = forward(cache, tok.view(1, 1), [cur_pos], plan).logits[:, -1, :]
+            # steady state (same plan, same cache length as the step before, one slot evicted per step): replay the graph
+            sig = (t_now, evict, plan.range_start)
+            if use_graph and evict and policy != "random" and not record and sig == prev_sig:
+                if graphed is None:
+                    graphed = GraphedStep(cache, plan, tok, cur_pos)
+                logits_last = graphed(tok, cur_pos)
+            else:
+                logits_last = forward(cache, tok.view(1, 1), [cur_pos], plan).logits[:, -1, :]
+            prev_sig = sig
             cur_pos += 1
         return out_ids
 

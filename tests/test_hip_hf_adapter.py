@@ -97,3 +97,34 @@ def test_streaming_through_the_hf_seam():
     with contextlib.redirect_stdout(io.StringIO()):
         ppl = model.easykv_ppl(input_ids=ids2, generation_config=dict(budget=0.5, kv_policy="roco", streaming=True))
     assert ppl > 1.0 and ppl == ppl
+
+
+@pytest.mark.parametrize("mode,cfg,prompt", [
+    ("auto", dict(budget=48, kv_policy="roco", max_new_tokens=40, recent_ratio=0.3), 120),
+    ("decoding", dict(budget=24, kv_policy="roco", max_new_tokens=64), 16),
+    ("decoding", dict(budget=24, kv_policy="h2o_head", max_new_tokens=64, streaming=True), 16),
+    ("auto", dict(budget=48, kv_policy="recency", max_new_tokens=24), 120),
+])
+def test_hipgraph_decode_step_equals_eager(mode, cfg, prompt):
+    """generation_config['hipgraph']: the steady-state decode step of the whole model replayed as one hipGraph
+     must produce the tokens, the retained slots and the score rows of the eager loop."""
+    import easykv_amd
+    from easykv_amd import hf
+    model = hf.patch_model(_tiny(3))
+    stride = 1 if mode == "decoding" else 8
+    easykv_amd.enable_fixed_kv(model, _Tok(), mode=mode, stride=stride)
+    ids = torch.randint(0, 97, (1, prompt), device="cuda")
+    runs = []
+    for use_graph in (False, True):
+        torch.manual_seed(11)     # the sampler draws from the global generator: same stream for both runs
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            out, cache = model.easykv_generate(input_ids=ids, generation_config=dict(cfg, eos_token_ids=[-1], temperature=0.7,
+                                                                                     hipgraph=use_graph), return_cache=True)
+        torch.cuda.synchronize()
+        b = cache.bank
+        t = cache.get_seq_length()
+        runs.append((out, buf.getvalue(), t, b.slot_of_pos[:, :, :t].clone(), b.score_sum[:, :, :t].clone(), b.ordered_kv()))
+    (o0, l0, t0, s0, sc0, kv0), (o1, l1, t1, s1, sc1, kv1) = runs
+    assert o0 == o1 and l0 == l1 and t0 == t1
+    assert torch.equal(s0, s1) and torch.equal(sc0, sc1)
+    assert torch.equal(kv0[0], kv1[0]) and torch.equal(kv0[1], kv1[1])

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--budget", type=int, default=2048)
     ap.add_argument("--stride", type=int, default=8)
     ap.add_argument("--new", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
     from transformers import LlamaConfig, LlamaForCausalLM
     import easykv_amd
@@ -67,10 +68,12 @@ def main():
     hf.patch_model(model)
     easykv_amd.enable_fixed_kv(model, Tok(), mode="auto", stride=args.stride)
 
+    use_graph = False
+
     def run(n):
         with contextlib.redirect_stdout(io.StringIO()) as buf:
             model.easykv_generate(input_ids=ids, generation_config=dict(budget=args.budget, kv_policy="roco", max_new_tokens=n,
-                                                                        temperature=1.0, eos_token_ids=[-1]))
+                                                                        temperature=1.0, eos_token_ids=[-1], hipgraph=use_graph))
         return buf.getvalue().strip()
 
     timed(lambda: run(4))
@@ -83,6 +86,16 @@ def main():
     res["easykv_amd_auto_roco"] = dict(decode_tok_s=args.new / (b - a), prefill_plus_8_s=a, printed=line,
                                        budget=args.budget, stride=args.stride)
     print("budgeted path:", res["easykv_amd_auto_roco"], flush=True)
+
+    # --- same, with the steady-state decode step of the whole model replayed as one hipGraph (generation_config['hipgraph'])
+    if not args.no_graph:
+        use_graph = True
+        timed(lambda: run(4))
+        a = timed(lambda: run(8))
+        b = timed(last)
+        res["easykv_amd_auto_roco_hipgraph"] = dict(decode_tok_s=args.new / (b - a), prefill_plus_8_s=a, printed=line,
+                                                    budget=args.budget, stride=args.stride)
+        print("budgeted path + hipGraph decode step:", res["easykv_amd_auto_roco_hipgraph"], flush=True)
     print(json.dumps(res))
 
 
