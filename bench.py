@@ -127,6 +127,8 @@ def strided_prefill(args, dev, n_chunks=24, warm=4):
     rnd = lambda h, n: torch.randn(L, h, n, D, generator=g, device=dev).half()
     bank = KVBank(L, Hq, H, D, cap=idx + stride, device=dev)
     bank.load_rows(rnd(H, idx), rnd(H, idx))          # state after the dense prefix and the fill-up chunks
+    if not args.identity_layout:                      # steady state of the chunk phase: rows recycled in place for many steps
+        bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=g, device=dev), dim=-1).int()
     bank.state_init(idx + stride, 2, stride)
     q, k, v = rnd(Hq, stride), rnd(H, stride), rnd(H, stride)
     plan = StepPlan(policy=args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco", phase="prefill", accumulate=True, evict=True,
@@ -153,7 +155,8 @@ def strided_prefill(args, dev, n_chunks=24, warm=4):
             "value": stride / (t_attn + t_score), "unit": "prompt tokens/s (chunk phase, attention/eviction path only)",
             "us_per_chunk_step": (t_attn + t_score) * 1e6, "attn_kernel_us": t_attn * 1e6, "score_select_us": t_score * 1e6,
             "algorithmic_bytes_per_step": by["total"] * L, "achieved_gbs": by["total"] * L / (t_attn + t_score) / 1e9,
-            "frac_of_hbm_peak": by["total"] * L / (t_attn + t_score) / 1e9 / HBM_PEAK_GBS, "chunk_steps_timed": len(ev)}
+            "frac_of_hbm_peak": by["total"] * L / (t_attn + t_score) / 1e9 / HBM_PEAK_GBS, "chunk_steps_timed": len(ev),
+            "slot_map": "identity" if args.identity_layout else "scattered"}
 
 
 def main():
@@ -178,6 +181,9 @@ def main():
     ap.add_argument("--overlap-scorer", action="store_true", help="split path: run the scorer on side streams, off the critical path")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
     ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0 (multi-rank smoke test on a 1-GPU box)")
+    ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed pre-warm of clocks and score state before the warmup steps (seconds)")
+    ap.add_argument("--identity-layout", action="store_true", help="start from a fresh bank's identity slot map (position order == "
+                    "address order) instead of the scattered steady-state layout")
     ap.add_argument("--graph", action="store_true", help="capture one step (all launches) in a hipGraph and replay it")
     args = ap.parse_args()
 
@@ -204,6 +210,12 @@ def main():
         lc = min(8, L - l0)
         bank.load_rows(torch.randn(lc, H, budget, D, generator=gen, device=dev).half(),
                        torch.randn(lc, H, budget, D, generator=gen, device=dev).half(), pos_begin=0, layer_begin=l0)
+    if not args.identity_layout:
+        # Long-run steady state: a score-driven policy recycles rows in place, so after a few thousand steps the birth order
+        # of the live rows is a random permutation of their addresses.  Start there instead of at the (sequential) identity
+        # layout a fresh bank has, so `--warmup` does not decide what is measured.
+        perm = torch.argsort(torch.rand(L, H, budget, generator=gen, device=dev), dim=-1).int()
+        bank.slot_of_pos[:, :, :budget] = perm
     bank.state_init(T, 0)
     qs = torch.randn(n_total, L, Hq, 1, D, generator=gen, device=dev).half()
     ks = torch.randn(n_total, L, H, 1, D, generator=gen, device=dev).half()
@@ -252,6 +264,18 @@ def main():
             # posted after this step's kernels, waited for at the next step, so the 8 KB transfer overlaps the next launch
             pending[:] = DS.ring_handoff_async(hidden, hidden_in, shard, pending)
 
+    # Clock / state pre-warm (untimed, before the W warmup steps): the same step for --prewarm-s seconds of wall time.  A cold
+    # GPU needs tens of ms of load before its clocks settle, and the roco state needs ~1000 steps to reach the steady state the
+    # policy lives in (low-mean tokens outside the feasible set accumulate), so neither depends on how small W is.
+    n_pre = 0
+    if args.prewarm_s > 0:
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm_s:
+            for _ in range(16):
+                step(n_pre % n_total)
+                n_pre += 1
+            torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
 
@@ -315,7 +339,7 @@ def main():
         t_attn = t_region if not per_step_events else (1.0 if args.overlap_scorer else sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3)
         cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={L} Hq={Hq} H={H} D={D} budget={budget} "
                            f"T={T} kv_policy={args.policy} (Llama2-7B shape, budget=50% of S=4096)",
-               "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [shard.begin, shard.end], "n_split": n_split, "fused": fused, "hipgraph": bool(args.graph), "overlap_scorer": bool(args.overlap_scorer),
+               "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [shard.begin, shard.end], "n_split": n_split, "fused": fused, "slot_map": "identity" if args.identity_layout else "scattered (random permutation: long-run steady state)", "prewarm_steps": n_pre, "hipgraph": bool(args.graph), "overlap_scorer": bool(args.overlap_scorer),
                "handoff": (world > 1 and not args.no_handoff and not args.graph)}
         line = {
             "metric": "decode_tokens_per_sec", "value": world * args.steps / elapsed, "unit": "tokens/s",

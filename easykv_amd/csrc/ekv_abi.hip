@@ -105,6 +105,17 @@ int check_layers(const ekv_bank* b, int begin, int count) {
 
 }  // namespace
 
+// Physical extent E of a step (every live row has a physical index < E): the caller's value when it is consistent, else cap.
+static int step_extent(const ekv_bank* bank, const ekv_step* st) {
+  return (st->phys_extent >= st->n_slots && st->phys_extent <= bank->cap) ? st->phys_extent : bank->cap;
+}
+
+// Pitch of a logits row in the fused decode kernel's LDS: logical positions (RoPE-on-read streams in position order, the
+// rotation needs the position index) or physical rows [0, E).
+int ekv_fused_logit_pad(const ekv_bank* bank, const ekv_step* st, int t_pad) {
+  return st->rope_on_read ? t_pad : (int)ekv_align((size_t)step_extent(bank, st), 64);
+}
+
 EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   EkvWs w{};
   const int T = st->n_slots;
@@ -121,7 +132,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   int n_split = st->n_split;
   w.fused_nw = ekv_decode_fused_nw(st->layer_count * bank->n_kv_heads);
   if (n_split <= 0 && st->q_len == 1 && st->layer_count * bank->n_kv_heads >= 256 && w.fused_nw == 8 &&
-      ekv_decode_fused_supported(bank->head_dim, rep, T, w.t_pad, st->n_evict, bank->cap, 8)) {
+      ekv_decode_fused_supported(bank->head_dim, rep, T, w.t_pad, ekv_fused_logit_pad(bank, st, w.t_pad), st->n_evict, bank->cap, 8)) {
     n_split = 1;   // >= 1 head per CU: one 8-wave workgroup per head beats key-range splits + a second kernel (GQA shapes)
   }
   if (n_split <= 0) {
@@ -198,7 +209,7 @@ int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, in
   const EkvWs ws = ekv_plan_workspace(bank, st, nullptr);
   *n_split = ws.n_split;
   *fused = (st->q_len == 1 && st->phases == 0 && st->n_split != -1 && ws.n_split == 1 &&
-            ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, st->n_evict, bank->cap, ws.fused_nw))
+            ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, ekv_fused_logit_pad(bank, st, ws.t_pad), st->n_evict, bank->cap, ws.fused_nw))
                ? 1 : 0;
   return EKV_OK;
 }
@@ -285,6 +296,8 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   aa.qb_rows = ws.qb_rows;
   aa.n_qblocks = ws.n_qblocks;
   aa.sm_div = st->sm_div;
+  aa.phys_extent = step_extent(bank, st);
+  aa.l_pad = ekv_fused_logit_pad(bank, st, ws.t_pad);
 
   EkvScoreArgs sa{};
   sa.slot_of_pos = bank->slot_of_pos;
@@ -324,7 +337,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
 
   // whole decode step in one launch when no head has to be split
   if (n == 1 && st->phases == 0 && ws.n_split == 1 &&
-      ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, st->n_evict, bank->cap, ws.fused_nw)) {
+      ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, aa.l_pad, st->n_evict, bank->cap, ws.fused_nw)) {
     return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, ws.fused_nw, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
 

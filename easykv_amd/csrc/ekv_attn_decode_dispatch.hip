@@ -4,22 +4,22 @@
 
 hipError_t ekv_launch_attn_decode_d32_plain(const EkvAttnArgs&, int, int, hipStream_t);
 hipError_t ekv_launch_decode_fused_d32_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
-size_t ekv_fused_lds_d32_plain(int, int, int);
+size_t ekv_fused_lds_d32_plain(int, int, int, int);
 hipError_t ekv_launch_attn_decode_d32_rope(const EkvAttnArgs&, int, int, hipStream_t);
 hipError_t ekv_launch_decode_fused_d32_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
-size_t ekv_fused_lds_d32_rope(int, int, int);
+size_t ekv_fused_lds_d32_rope(int, int, int, int);
 hipError_t ekv_launch_attn_decode_d64_plain(const EkvAttnArgs&, int, int, hipStream_t);
 hipError_t ekv_launch_decode_fused_d64_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
-size_t ekv_fused_lds_d64_plain(int, int, int);
+size_t ekv_fused_lds_d64_plain(int, int, int, int);
 hipError_t ekv_launch_attn_decode_d64_rope(const EkvAttnArgs&, int, int, hipStream_t);
 hipError_t ekv_launch_decode_fused_d64_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
-size_t ekv_fused_lds_d64_rope(int, int, int);
+size_t ekv_fused_lds_d64_rope(int, int, int, int);
 hipError_t ekv_launch_attn_decode_d128_plain(const EkvAttnArgs&, int, int, hipStream_t);
 hipError_t ekv_launch_decode_fused_d128_plain(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
-size_t ekv_fused_lds_d128_plain(int, int, int);
+size_t ekv_fused_lds_d128_plain(int, int, int, int);
 hipError_t ekv_launch_attn_decode_d128_rope(const EkvAttnArgs&, int, int, hipStream_t);
 hipError_t ekv_launch_decode_fused_d128_rope(const EkvAttnArgs&, const EkvScoreArgs&, int, int, int, hipStream_t);
-size_t ekv_fused_lds_d128_rope(int, int, int);
+size_t ekv_fused_lds_d128_rope(int, int, int, int);
 
 bool ekv_attn_decode_supported(int head_dim, int rep) {
   return (head_dim == 32 || head_dim == 64 || head_dim == 128) && (rep == 1 || rep == 2 || rep == 4 || rep == 8);
@@ -43,14 +43,14 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 // nw = 4: up to four workgroups per CU (LDS <= 80 KB keeps >= 2); nw = 8: one or two workgroups per CU.
 int ekv_decode_fused_nw(int n_heads_in_launch) { return (n_heads_in_launch >= 256 && n_heads_in_launch <= 512) ? 8 : 4; }
 
-bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap, int nw) {
+bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int l_pad, int n_evict, int cap, int nw) {
   // (the slot map and the score rows are fetched 16 bytes at a time: rows must be 16-byte aligned)
   if (!ekv_attn_decode_supported(head_dim, rep) || n_evict > 1 || n_slots > 256 * 24 || (cap & 3) != 0 || cap < 16) return false;
   size_t lds = 1 << 30;
   switch (head_dim) {
-    case 32: lds = ekv_fused_lds_d32_plain(rep, t_pad, nw); break;
-    case 64: lds = ekv_fused_lds_d64_plain(rep, t_pad, nw); break;
-    case 128: lds = ekv_fused_lds_d128_plain(rep, t_pad, nw); break;
+    case 32: lds = ekv_fused_lds_d32_plain(rep, t_pad, l_pad, nw); break;
+    case 64: lds = ekv_fused_lds_d64_plain(rep, t_pad, l_pad, nw); break;
+    case 128: lds = ekv_fused_lds_d128_plain(rep, t_pad, l_pad, nw); break;
   }
   return lds <= (nw == 8 ? 150 : 80) * 1024;   // 80 KB still leaves two 4-wave workgroups per CU
 }

@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(kSNT) ekv_decode_score_kernel(const EkvScoreAr
     sc.out[(hq0 + r) * D + d] = __float2half(ekv_fold_partials(sc.partials + ((hq0 + r) * sc.n_split) * PS, sc.n_split, PS, d));
   }
   __syncthreads();   // LDS-DMA complete (vmcnt(0) before the barrier) and visible
-  ekv_decode_tail<REP, ITEMS, kSNW>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red);
+  uint32_t* s_hist = reinterpret_cast<uint32_t*>(red.buf + 2 * kSNW * 8);     // roco select scratch: histogram, candidate list
+  unsigned long long* s_list = reinterpret_cast<unsigned long long*>(s_hist + 264);
+  ekv_decode_tail<REP, ITEMS, kSNW>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red, s_hist, s_list, kSNT);
 }
 
 // Partials of the key-range splits -> fp16 attention output, nothing else (rows = q_len * n_q_heads per layer).
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(128) ekv_fold_kernel(const EkvScoreArgs sc) {
 
 size_t score_lds(int rep, int t_pad, int policy) {
   const size_t n_state = policy == EKV_POLICY_ROCO ? 3 : 1;
-  return ((size_t)rep * t_pad + n_state * ekv_align((size_t)t_pad, 256)) * 4 + 2 * kSNW * 8 * 8;
+  return ((size_t)rep * t_pad + n_state * ekv_align((size_t)t_pad, 256)) * 4 + 2 * kSNW * 8 * 8 + 264 * 4 + kSNT * 8;
 }
 
 template <int REP, int ITEMS>

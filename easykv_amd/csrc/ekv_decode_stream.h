@@ -23,13 +23,22 @@ struct EkvDecodeGeom {
 // Streams positions [t0, t1) of KV head h.  SLOT_LDS: s_slot holds slot_of_pos[t0..t1) in LDS; otherwise s_slot is
 // the head's row of the global slot map (t0 must be a multiple of 8) and the 8 indices of a lane group are fetched
 // one iteration ahead.  Logits (q.k / sm_div) go to `logit_out` (+ `logit_stride` per query head): workspace or LDS.
-template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4>
+//
+// PHYS (fused kernel, t0 = 0, t1 = T): the rows are streamed in PHYSICAL order, 0 .. a.phys_extent-1, not through the slot
+// map.  Eviction recycles rows in place, so after a few thousand steps of a score-driven policy the birth order of the
+// live rows is a random permutation of their addresses; gathering 256-byte rows in that order costs 16-18 % of the
+// bandwidth (measured: 188 -> 223 us per launch after 4000 steps), while attention does not care about the order.
+// `s_dead` (LDS, one bit per row) marks free rows, the row the new token is being written to and the padding past the
+// extent; logits are stored at the PHYSICAL row index (the scorer tail reads them back through the slot map).
+template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4, bool PHYS = false>
 __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
                                                   int logit_stride, int t0, int t1_in, int ll, int h, size_t head_row,
-                                                  float (&m)[REP], float (&l)[REP], float (&o)[REP][8]) {
+                                                  float (&m)[REP], float (&l)[REP], float (&o)[REP][8],
+                                                  const uint8_t* s_dead = nullptr) {
   using Gm = EkvDecodeGeom<D, NW>;
   constexpr int LPR = Gm::LPR, RW = Gm::RW;
   constexpr int kNW = NW;
+  static_assert(!(PHYS && (ROPE || SLOT_LDS)), "physical-order streaming: plain keys, global slot map");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int t_new = a.n_slots - 1;  // the appended position
@@ -113,19 +122,20 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         acc = ekv_dot8(qv[r], kn, 0.f);
       }
       acc = ekv_group_sum<LPR>(acc) / a.sm_div;
-      if (logit_out != nullptr && sub == 0) logit_out[(size_t)r * logit_stride + t_new] = acc;
+      if (logit_out != nullptr && sub == 0) logit_out[(size_t)r * logit_stride + (PHYS ? s_slot[t_new] : t_new)] = acc;
       m[r] = acc;      // p = exp(acc - m) = 1
       l[r] = 1.f;
       ekv_axpy8(1.f, vn, o[r]);
     }
   }
-  if (t1 <= t0) return;   // the split held only the appended row
+  if (!PHYS && t1 <= t0) return;   // the split held only the appended row
 
   static_assert(kU == 8, "index prefetch assumes 8 rows per lane group");
-  const int last_slot = s_slot[t1 - 1 - slot_base];
+  if (PHYS) t1 = a.phys_extent;   // loop bound: physical rows [0, E); which of them count is s_dead's business
+  const int last_slot = PHYS ? 0 : s_slot[t1 - 1 - slot_base];
   const int idx_cap = (a.cap - 8) & ~7;   // prefetches past t1 stay inside the head's map row (values unused)
   uint4 ia = {0, 0, 0, 0}, ib = {0, 0, 0, 0};   // !SLOT_LDS: slot indices of rows j0..j0+7 of the next iteration
-  if (!SLOT_LDS && t0 + wave * RW < t1) {
+  if (!PHYS && !SLOT_LDS && t0 + wave * RW < t1) {
     const uint4* ip = reinterpret_cast<const uint4*>(s_slot + min(t0 + wave * RW + grp * kU, idx_cap));
     ia = ip[0];
     ib = ip[1];
@@ -134,7 +144,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     uint4 kr[kU], vr[kU];
     const int j0 = base + grp * kU;
     const int cur[8] = {(int)ia.x, (int)ia.y, (int)ia.z, (int)ia.w, (int)ib.x, (int)ib.y, (int)ib.z, (int)ib.w};
-    if (!SLOT_LDS && base + kNW * RW < t1) {     // next iteration's indices (the map row has >= t_pad entries)
+    if (!PHYS && !SLOT_LDS && base + kNW * RW < t1) {     // next iteration's indices (the map row has >= t_pad entries)
       const uint4* ip = reinterpret_cast<const uint4*>(s_slot + min(j0 + kNW * RW, idx_cap));
       ia = ip[0];
       ib = ip[1];
@@ -143,13 +153,20 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     for (int u = 0; u < kU; ++u) {
       const int j = j0 + u;
       const int jj = j < t1 ? j : t1 - 1;
-      const int row = SLOT_LDS ? s_slot[jj - t0] : (j < t1 ? cur[u] : last_slot);
+      const int row = PHYS ? jj : (SLOT_LDS ? s_slot[jj - t0] : (j < t1 ? cur[u] : last_slot));
       const __half* kp = a.k + (head_row + row) * D;
       const __half* vp = a.v + (head_row + row) * D;
       // K/V rows are read exactly once per step and the cache (>1 GB) never fits L2/MALL: non-temporal loads
       // (measured on MI355X: 5.5 -> 6.1 TB/s on the pure stream)
       kr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(kp) + sub));
       vr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(vp) + sub));
+    }
+    // PHYS: bit u of dead8 = row j0+u is free / being appended / past the extent (j0 is a multiple of 8: one mask byte)
+    const unsigned dead8 = PHYS ? s_dead[j0 >> 3] : 0u;
+    if (PHYS && dead8 != 0u) {   // rare: a dead row may hold anything (0 * inf = NaN in the PV accumulation)
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if ((dead8 >> u) & 1u) vr[u] = uint4{0, 0, 0, 0};
     }
     float sall[ROPE ? REP : 1][kU];   // ROPE: every row is rotated once, then dotted with all REP queries
     if (ROPE) {
@@ -177,7 +194,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         } else {
           float acc = ekv_dot8(qv[r], kr[u], 0.f);
           acc = ekv_group_sum<LPR>(acc);
-          s[u] = (j0 + u < t1) ? acc / a.sm_div : EKV_NEG_INF;
+          s[u] = (PHYS ? !((dead8 >> u) & 1u) : (j0 + u < t1)) ? acc / a.sm_div : EKV_NEG_INF;
         }
       }
       // export the raw logits: lane `sub` of the group owns row j0+sub -> 8 consecutive floats per group
@@ -189,7 +206,8 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         float mine = s[0];
 #pragma unroll
         for (int u = 1; u < kU; ++u) mine = (mu == u) ? s[u] : mine;
-        if (logit_out != nullptr && mu < kU && j0 + mu < t1) logit_out[(size_t)r * logit_stride + j0 + mu] = mine;
+        if (logit_out != nullptr && mu < kU && (PHYS ? !((dead8 >> mu) & 1u) : (j0 + mu < t1)))
+          logit_out[(size_t)r * logit_stride + j0 + mu] = mine;
       }
       float mx = s[0];
 #pragma unroll

@@ -62,6 +62,25 @@ struct RedN {  // block reductions for an NW-wave workgroup; scratch = 2 x NW x 
     for (int w = 0; w < NW; ++w) y += r[w];
     return y;
   }
+  // block-wide minimum of two independent uint32 values in one barrier
+  __device__ __forceinline__ void min2_u32(uint32_t& a, uint32_t& b) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a = min(a, (uint32_t)__shfl_xor((int)a, off, 64));
+      b = min(b, (uint32_t)__shfl_xor((int)b, off, 64));
+    }
+    uint32_t* r = reinterpret_cast<uint32_t*>(slot());
+    if (lane == 0) {
+      r[wave * 2] = a;
+      r[wave * 2 + 1] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      a = min(a, r[w * 2]);
+      b = min(b, r[w * 2 + 1]);
+    }
+  }
   __device__ __forceinline__ unsigned long long min_u64(unsigned long long x) {
     x = ekv_wave_min_u64(x);
     unsigned long long* r = slot();
@@ -98,9 +117,13 @@ __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, s
   }
 }
 
-template <int REP, int ITEMS, int NW = 4>
+// PHYS: s_logit is indexed by PHYSICAL row (the fused kernel streamed the rows in address order); the logit of position
+// j sits at s_logit[slot_of_pos[j]].  The passes below still run in position order with the same thread <-> column
+// mapping, so sums are formed in exactly the order of the position-indexed variant (bit-identical scores).
+template <int REP, int ITEMS, int NW = 4, bool PHYS = false>
 __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, int h, size_t head_row, int T, int off, int W,
-                                                float* s_logit, int t_pad, float* sS, float* sQ, float* sC, RedN<NW>& red) {
+                                                float* s_logit, int t_pad, float* sS, float* sQ, float* sC, RedN<NW>& red,
+                                                uint32_t* s_hist, unsigned long long* s_list, int list_cap) {
   const int tid = threadIdx.x;
   constexpr int NT = 64 * NW;
   const bool roco = sc.policy == EKV_POLICY_ROCO;
@@ -115,35 +138,88 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
     float mx[REP], sm[REP];
 #pragma unroll
     for (int r = 0; r < REP; ++r) mx[r] = EKV_NEG_INF, sm[r] = 0.f;
-#pragma unroll 4
-    for (int j = tid; j < T; j += NT) {
+    // PHYS: cell of position j (this thread's columns j = tid + NT*it) and of position off + j, loaded together
+    // (unconditional, clamped: predicated loads get serialised by hipcc)
+    const int32_t* map_c = sc.slot_of_pos + head_row;
+    int cell[PHYS ? ITEMS : 1], cell_off[PHYS ? ITEMS : 1];
+    if (PHYS) {
 #pragma unroll
-      for (int r = 0; r < REP; ++r) mx[r] = fmaxf(mx[r], s_logit[(size_t)r * t_pad + j]);
+      for (int it = 0; it < ITEMS; ++it) cell[it] = map_c[min(tid + it * NT, T - 1)];
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) cell_off[it] = off == 0 ? cell[it] : map_c[min(off + tid + it * NT, T - 1)];
+    }
+    if (PHYS) {
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        if (tid + it * NT < T) {
+#pragma unroll
+          for (int r = 0; r < REP; ++r) mx[r] = fmaxf(mx[r], s_logit[(size_t)r * t_pad + cell[it]]);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int j = tid; j < T; j += NT) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) mx[r] = fmaxf(mx[r], s_logit[(size_t)r * t_pad + j]);
+      }
     }
     red.template max_n<REP>(mx);
-#pragma unroll 4
-    for (int j = tid; j < T; j += NT) {      // e = exp(x - max) once: it replaces the logit in LDS
+    if (PHYS) {
 #pragma unroll
-      for (int r = 0; r < REP; ++r) {
-        const float e = expf(s_logit[(size_t)r * t_pad + j] - mx[r]);
-        s_logit[(size_t)r * t_pad + j] = e;
-        sm[r] += e;
+      for (int it = 0; it < ITEMS; ++it) {
+        if (tid + it * NT < T) {
+#pragma unroll
+          for (int r = 0; r < REP; ++r) {
+            const float e = expf(s_logit[(size_t)r * t_pad + cell[it]] - mx[r]);
+            s_logit[(size_t)r * t_pad + cell[it]] = e;
+            sm[r] += e;
+          }
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int j = tid; j < T; j += NT) {      // e = exp(x - max) once: it replaces the logit in LDS
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+          const float e = expf(s_logit[(size_t)r * t_pad + j] - mx[r]);
+          s_logit[(size_t)r * t_pad + j] = e;
+          sm[r] += e;
+        }
       }
     }
     red.template sum_n<REP>(sm);
     // off + j == a column this thread wrote itself only when off % NT == 0; otherwise wait for the other writers
     if ((off % NT) != 0) __syncthreads();
-#pragma unroll 4
-    for (int j = tid; j < W; j += NT) {
-      float pb = 0.f;
+    if (PHYS) {
 #pragma unroll
-      for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + off + j] / sm[r];
-      if (REP > 1) pb = pb / (float)REP;
-      if (sc.policy == EKV_POLICY_TOVA) {
-        sS[j] = pb;
-      } else {
-        sS[j] += pb;
-        if (roco) sQ[j] += pb * pb;
+      for (int it = 0; it < ITEMS; ++it) {
+        const int j = tid + it * NT;
+        if (j < W) {
+          float pb = 0.f;
+#pragma unroll
+          for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + cell_off[it]] / sm[r];
+          if (REP > 1) pb = pb / (float)REP;
+          if (sc.policy == EKV_POLICY_TOVA) {
+            sS[j] = pb;
+          } else {
+            sS[j] += pb;
+            if (roco) sQ[j] += pb * pb;
+          }
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int j = tid; j < W; j += NT) {
+        float pb = 0.f;
+#pragma unroll
+        for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + off + j] / sm[r];
+        if (REP > 1) pb = pb / (float)REP;
+        if (sc.policy == EKV_POLICY_TOVA) {
+          sS[j] = pb;
+        } else {
+          sS[j] += pb;
+          if (roco) sQ[j] += pb * pb;
+        }
       }
     }
   }
@@ -157,7 +233,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
     } else if (roco) {
       // std keys overwrite the (dead) first logit row at the thread's own columns
       uint32_t* kstd = reinterpret_cast<uint32_t*>(s_logit);
-      if ((off % NT) != 0) __syncthreads();   // all e's consumed before their cells are reused
+      if (PHYS || (off % NT) != 0) __syncthreads();   // all e's consumed before their cells are reused
   #pragma unroll 4
     for (int j = tid; j < W; j += NT) {
         const float c = sC[j] + sc.count_add;
@@ -167,33 +243,78 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
         if (j >= W - sc.roco_tail || j < sc.win_lo) sd = 1e9f;
         kstd[j] = ekv_fkey(sd);
       }
-      // victim = argmin mean over F = {k1 smallest std}: walk candidates in increasing (mean, index) order,
-      // take the first whose std rank is < k1 (three block reductions per try instead of a k-select)
-      int excl[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) excl[i] = -1;
-#pragma unroll
-      for (int attempt = 0; attempt < 8; ++attempt) {
-        if (victim >= 0) break;
-        unsigned long long best = ~0ull;
-    #pragma unroll 4
-    for (int j = tid; j < W; j += NT) {
-          bool dropped = false;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) dropped |= (i < attempt && excl[i] == j);
-          const unsigned long long x = ((unsigned long long)ekv_fkey(sS[j] / sC[j]) << 32) | (uint32_t)j;
-          if (!dropped) best = x < best ? x : best;
+      // victim = argmin mean over F = {the k1 smallest std, ties to the lower index} (easykv/easykv.py:319-326).
+      // F = {j : (key_j, j) < thr} where thr - 1 is the element of rank k1 - 1 in (key, index) order.  (An earlier version
+      // walked the candidates in increasing mean and tested each one's std rank; in steady state that always fails: the
+      // policy itself keeps the low-mean tokens that are NOT in F alive, so the bottom of the mean order fills up with them
+      // and every step fell through to a 32-pass bisection, 65 us per workgroup after ~1000 steps.)
+      // Exact select in five barriers: range of the real keys -> 256-bin histogram -> the bin holding rank k1 - 1 ->
+      // its (<= list_cap) members ranked against each other.
+      const uint32_t kSent = ekv_fkey(1e9f);   // the 1e9 sentinels and NaN (0xFFFFFFFF) sort above every real std
+      unsigned long long thr = 0;              // exclusive threshold on (key << 32 | j); 0 = not found yet
+      {
+        uint32_t kmin = ~0u, nmax = ~0u;       // nmax = ~max
+  #pragma unroll 4
+        for (int j = tid; j < W; j += NT) {
+          const uint32_t k = kstd[j];
+          if (k < kSent) {
+            kmin = min(kmin, k);
+            nmax = min(nmax, ~k);
+          }
         }
-        const int cand = (int)(red.min_u64(best) & 0xFFFFFFFFu);
-        const uint32_t sk = kstd[cand];          // written before the barrier inside min_u64
-        int c = 0;
-#pragma unroll 4
-        for (int j = tid; j < W; j += NT) c += (kstd[j] < sk || (kstd[j] == sk && j < cand)) ? 1 : 0;
-        if (red.sum_int(c) < sc.roco_k1) victim = cand;
-        else excl[attempt] = cand;               // not feasible: drop it from the walk
+        if (tid < 256) s_hist[tid] = 0;
+        if (tid < 8) s_hist[256 + tid] = 0;    // [256] members listed so far, [257] bin, [258] below, [260..261] result
+        red.min2_u32(kmin, nmax);              // (its barrier also publishes the zeroed histogram)
+        const uint32_t kmax = ~nmax;
+        if (kmin <= kmax) {
+          const uint32_t range = kmax - kmin;
+          const int shift = range < 256u ? 0 : 24 - __clz(range);     // range >> shift < 256
+          auto bin_of = [&](uint32_t k) { return k >= kSent ? 255u : min(255u, (k - kmin) >> shift); };
+  #pragma unroll 4
+          for (int j = tid; j < W; j += NT) atomicAdd(&s_hist[bin_of(kstd[j])], 1u);
+          __syncthreads();
+          if (tid < 64) {                      // wave 0: lane l owns bins 4l .. 4l+3; inclusive scan over the lanes
+            const uint32_t c0 = s_hist[4 * tid], c1 = s_hist[4 * tid + 1], c2 = s_hist[4 * tid + 2], c3 = s_hist[4 * tid + 3];
+            uint32_t incl = c0 + c1 + c2 + c3;
+            const uint32_t mine = incl;
+  #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+              if (tid >= o) incl += up;
+            }
+            const uint32_t excl = incl - mine, k1 = (uint32_t)sc.roco_k1;
+            if (excl < k1 && k1 <= incl) {     // exactly one lane: the bin where the cumulative count reaches k1
+              uint32_t below = excl, b = 4 * tid;
+              if (below + c0 < k1) { below += c0; ++b;
+                if (below + c1 < k1) { below += c1; ++b;
+                  if (below + c2 < k1) { below += c2; ++b; } } }
+              s_hist[257] = b;
+              s_hist[258] = below;
+            }
+          }
+          __syncthreads();
+          const uint32_t b_sel = s_hist[257], below = s_hist[258], in_bin = s_hist[b_sel];
+          if ((int)in_bin <= list_cap && (int)in_bin <= NT) {
+  #pragma unroll 4
+            for (int j = tid; j < W; j += NT) {
+              const uint32_t k = kstd[j];
+              if (bin_of(k) == b_sel) s_list[atomicAdd(&s_hist[256], 1u)] = ((unsigned long long)k << 32) | (uint32_t)j;
+            }
+            __syncthreads();
+            if (tid < (int)in_bin) {
+              const unsigned long long e = s_list[tid];
+              uint32_t rank = 0;
+              for (int i = 0; i < (int)in_bin; ++i) rank += s_list[i] < e ? 1u : 0u;
+              if (below + rank == (uint32_t)sc.roco_k1 - 1u) *reinterpret_cast<unsigned long long*>(s_hist + 260) = e + 1ull;
+            }
+            __syncthreads();
+            thr = *reinterpret_cast<const unsigned long long*>(s_hist + 260);
+          }
+        }
       }
-      if (victim < 0) {
-        // fallback: explicit k1-select on the std keys (bitwise bisection), then argmin mean over the set
+      if (thr == 0) {
+        // fallback (threshold bin too crowded, e.g. all keys equal in the first steps; or no real key at all): explicit
+        // k1-select on the std keys by bitwise bisection
         uint32_t tau = 0;
         for (int bit = 31; bit >= 0; --bit) {
           const uint32_t t = tau | (1u << bit);
@@ -221,10 +342,13 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
           }
           bound = lo;
         }
+        thr = ((unsigned long long)tau << 32) | (uint32_t)bound;
+      }
+      {
         unsigned long long best = ~0ull;
     #pragma unroll 4
     for (int j = tid; j < W; j += NT) {
-          const bool feas = kstd[j] < tau || (kstd[j] == tau && j < bound);
+          const bool feas = (((unsigned long long)kstd[j] << 32) | (uint32_t)j) < thr;
           const unsigned long long x = ((unsigned long long)ekv_fkey(sS[j] / sC[j]) << 32) | (uint32_t)j;
           if (feas) best = x < best ? x : best;
         }

@@ -46,6 +46,8 @@ struct EkvAttnArgs {
   int32_t n_col_parts;   // = query-tile waves per workgroup (2 or 4) * n_qblocks
   int32_t n_q_heads, n_kv_heads, cap, n_slots, q_len, n_split, rows_per_split, t_pad, layer_begin, causal;
   int32_t qb_rows, n_qblocks;  // chunk kernels: queries per query block, number of query blocks
+  int32_t phys_extent;         // fused decode step, physical-order stream: live rows have physical index < phys_extent
+  int32_t l_pad;               // fused decode step: pitch of a logits row in LDS (t_pad, or align(phys_extent, 64))
   float sm_div;
 };
 
@@ -78,7 +80,8 @@ hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipS
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 bool ekv_attn_decode_supported(int head_dim, int rep);
 int ekv_decode_fused_nw(int n_heads_in_launch);
-bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int n_evict, int cap, int nw);
+bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int l_pad, int n_evict, int cap, int nw);
+int ekv_fused_logit_pad(const ekv_bank* bank, const ekv_step* st, int t_pad);
 hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, int nw, hipStream_t s);
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len);
 void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw);

@@ -64,6 +64,10 @@ class KVBank:
         self.score_sq = torch.zeros_like(self.score_sum) if scored else None
         self.score_cnt = torch.zeros_like(self.score_sum) if scored else None
         self.n_slots = [0] * n_layers
+        # High-water mark of live rows per layer.  The library keeps the free list as [freed rows (most recent first), never-
+        # used rows ascending] and appends take from its front, so every live row has a physical index < extent: the
+        # one-launch decode step streams the rows [0, extent) in address order (ekv_step.phys_extent).
+        self.extent = [0] * n_layers
         self._ws = None
         # scorer off the critical path (attend(..., overlap_scorer=True)): side streams, a ring of workspaces and, per
         # layer, the event after which its slot map / score rows are up to date again
@@ -90,6 +94,7 @@ class KVBank:
     def reset(self):
         check(self.lib.ekv_bank_reset(C.byref(self._bank), self._stream()), "ekv_bank_reset")
         self.n_slots = [0] * self.n_layers
+        self.extent = [0] * self.n_layers
 
     def state_init(self, width, mode, stride=1, layer_begin=0, layer_count=None):
         """mode 0 decoding (easykv/easykv.py:242-245); 1 prefill+keep_attention; 2 prefill (:412-416)."""
@@ -111,6 +116,7 @@ class KVBank:
         check(self.lib.ekv_scatter_rows(C.byref(self._bank), layer_begin, lc, pos, n, _ptr(k), _ptr(v), self._stream()), "ekv_scatter_rows")
         for l in range(layer_begin, layer_begin + lc):
             self.n_slots[l] = pos + n
+            self.extent[l] = max(self.extent[l], pos + n)
 
     def ordered_kv(self, layer_begin=0, layer_count=None):
         """The ordered ``[layers, H, T, D]`` view the HF legacy tuple needs (birth order)."""
@@ -146,6 +152,7 @@ class KVBank:
         st.tova_head_mean = int(plan.tova_head_mean)
         st.roco_tail = ROCO_TAIL
         st.range_start = -1
+        st.phys_extent = max(max(self.extent[layer_begin:layer_begin + layer_count]), t)
         if plan.evict and st.policy != _lib.POLICY_NONE:
             if plan.phase == "decode":
                 rw = int(plan.budget * DECODE_RECENT_RATIO)
@@ -225,6 +232,7 @@ class KVBank:
             self._attend_overlapped(st, q, k_new, v_new, out, evict_ids, lc, layer_begin)
             for l in range(layer_begin, layer_begin + lc):
                 self.n_slots[l] = st.n_slots - st.n_evict
+                self.extent[l] = st.phys_extent
             return out, (evict_ids if st.n_evict > 0 else None)
         if any(ev is not None for ev in self._score_done[layer_begin:layer_begin + lc]):
             self.join()
@@ -236,4 +244,6 @@ class KVBank:
         if phases != 1:     # phases == 1 launches the attention kernel only; the slot map is untouched
             for l in range(layer_begin, layer_begin + lc):
                 self.n_slots[l] = st.n_slots - st.n_evict
+        for l in range(layer_begin, layer_begin + lc):      # the new rows are written by the attention kernel
+            self.extent[l] = st.phys_extent
         return out, (evict_ids if st.n_evict > 0 else None)

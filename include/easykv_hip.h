@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EKV_ABI_VERSION 1
+#define EKV_ABI_VERSION 2
 
 /* kv_policy strings of the reference -> codes (easykv/easykv.py:288-300, :310-362) */
 enum {
@@ -95,6 +95,12 @@ typedef struct ekv_step {
   float sm_div;         /* logits are divided by this (sqrt(head_dim))                                   */
   int32_t two_pass;     /* scored chunk steps: 0 = library decides, 1 = statistics pass + exact pass with in-kernel
                            column sums whenever the shape allows it, -1 = always one pass with exported logits     */
+  int32_t phys_extent;  /* E: every live row of these layers has a physical index < E (n_slots <= E <= cap), and rows
+                           [0, E) hold initialised memory.  0 = unknown (cap is used).  The one-launch decode step streams
+                           the rows [0, E) in PHYSICAL order (sequential HBM reads however fragmented the slot map is) and
+                           masks the dead ones, so a tight E saves reading free rows.  With the free list kept as this
+                           library keeps it (freed rows first, then never-used rows ascending) E is simply the high-water
+                           mark of n_slots.                                                                          */
 } ekv_step;
 
 int ekv_abi_version(void);

@@ -123,3 +123,95 @@ def test_eight_wave_fused_kernel_for_launches_with_one_or_two_heads_per_cu(hq, h
             assert torch.allclose(o_f[l].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4)
     assert torch.equal(banks["fused"].slot_of_pos, banks["split"].slot_of_pos)
     assert torch.allclose(banks["fused"].score_sum, banks["split"].score_sum, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("hq,h,d,L,policy,holes", [(8, 8, 128, 8, "roco", 37), (8, 4, 64, 4, "roco", 5), (16, 2, 32, 3, "h2o_head", 90),
+                                                   (4, 4, 128, 64, "roco", 1), (32, 4, 128, 2, "tova", 64), (8, 8, 128, 40, "recency", 12)])
+def test_physical_order_stream_with_a_scattered_slot_map(hq, h, d, L, policy, holes):
+    """The one-launch decode step streams the K/V rows in PHYSICAL order and masks the dead ones (free rows, the row being
+    appended, the padding past the extent).  Worst case here: the live rows are a random subset of the bank's rows in a random
+    order, the free rows in between hold NaN / inf garbage, and the extent is unknown (= cap).  Same trajectory as the
+    position-ordered split path and the oracle; the natural case (extent tracked by KVBank, holes left by a chunk phase) follows."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    budget, steps, P = 150, 24, (0 if policy == "recency" else 7)
+    g = torch.Generator().manual_seed(hq * 11 + d + holes)
+    T0 = P + budget
+    cap = T0 + 1 + holes
+    k0, v0 = torch.randn(L, h, T0, d, generator=g).half(), torch.randn(L, h, T0, d, generator=g).half()
+    warm = torch.rand(L, h, budget + 1, generator=g) * 1e-3
+    banks = {}
+    for name in ("fused", "split"):
+        b = KVBank(L, hq, h, d, cap=cap)
+        # scatter: logical position j lives in physical row perm[j]; rows perm[T0:] are free and poisoned
+        gp = torch.Generator().manual_seed(99)
+        perm = torch.stack([torch.randperm(b.cap, generator=gp) for _ in range(L * h)]).view(L, h, b.cap).int().cuda()
+        b.slot_of_pos.copy_(perm)
+        b.k.fill_(float("nan"))
+        b.v.fill_(float("inf"))
+        b.load_rows(k0.cuda(), v0.cuda())          # goes through the slot map
+        b.extent = [b.cap] * L                      # the free list is not in library order any more: extent unknown
+        if policy != "recency":
+            b.state_init(budget + 1, 0)
+            b.score_sum[:, :, :budget + 1] += warm.cuda()
+            b.score_sq[:, :, :budget + 1] += (warm ** 2).cuda()
+        banks[name] = b
+    kw = dict(policy=policy, phase="decode", evict=True, score_off=P, budget=budget)
+    if policy == "recency":
+        kw["range_start"] = 0
+    assert banks["fused"].step_plan(StepPlan(n_split=1, **kw), 1) == (1, True)
+    n_check = min(2, L)
+    sts = []
+    for l in range(n_check):
+        st = O.LayerState(k=k0[l:l + 1].float(), v=v0[l:l + 1].float())
+        if policy != "recency":
+            st.s, st.q, st.c = O.init_state_decoding((h,), budget)
+            st.s += warm[l]
+            st.q += warm[l] ** 2
+        sts.append(st)
+    for i in range(steps):
+        q, k, v = (torch.randn(L, n, 1, d, generator=g).half() for n in (hq, h, h))
+        o_f, i_f = banks["fused"].attend(StepPlan(n_split=1, **kw), q.cuda(), k.cuda(), v.cuda())
+        o_s, i_s = banks["split"].attend(StepPlan(n_split=2, **kw), q.cuda(), k.cuda(), v.cuda())
+        assert torch.equal(i_f, i_s), i
+        assert torch.isfinite(o_f.float()).all()
+        assert torch.allclose(o_f.float(), o_s.float(), atol=1e-3, rtol=5e-4)
+        for l in range(n_check):
+            o_ref, ids_ref = O.layer_step(sts[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw))
+            assert torch.allclose(o_f[l].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4)
+    assert torch.equal(banks["fused"].slot_of_pos, banks["split"].slot_of_pos)
+    if policy != "recency":
+        assert torch.equal(banks["fused"].score_sum, banks["split"].score_sum)     # same summation order: bit-identical
+    kf, vf = banks["fused"].ordered_kv()
+    ks, vs = banks["split"].ordered_kv()
+    assert torch.equal(kf, ks) and torch.equal(vf, vs)
+
+
+def test_physical_order_stream_after_a_chunk_phase_leaves_holes():
+    """auto-mode shape: a strided chunk phase (8 victims per step) followed by single-token decode — the decode steps run
+    with 7 permanent holes below KVBank's tracked extent.  Fused (physical order) vs split (position order), 200 steps."""
+    from easykv_amd import KVBank, StepPlan
+    L, hq, h, d, stride, idx = 16, 8, 8, 128, 8, 120
+    g = torch.Generator().manual_seed(5)
+    banks = {n: KVBank(L, hq, h, d, cap=idx + stride + 1) for n in ("fused", "split")}
+    k0, v0 = torch.randn(L, h, idx, d, generator=g).half(), torch.randn(L, h, idx, d, generator=g).half()
+    for b in banks.values():
+        b.load_rows(k0.cuda(), v0.cuda())
+        b.state_init(idx + stride, 2, stride)
+    pre = dict(policy="roco", phase="prefill", accumulate=True, evict=True, budget=idx + stride, recent=12, sink=4, stride=stride)
+    for i in range(6):
+        q, k, v = (torch.randn(L, n, stride, d, generator=g).half() for n in (hq, h, h))
+        outs = [b.attend(StepPlan(**pre), q.cuda(), k.cuda(), v.cuda()) for b in banks.values()]
+        assert torch.equal(outs[0][1], outs[1][1])
+    assert banks["fused"].extent == [idx + stride] * L and banks["fused"].n_slots == [idx] * L
+    dec = dict(policy="roco", phase="decode", evict=True, score_off=0, budget=idx + stride)
+    assert banks["fused"].step_plan(StepPlan(n_split=1, **dec), 1) == (1, True)
+    for i in range(200):
+        q, k, v = (torch.randn(L, n, 1, d, generator=g).half() for n in (hq, h, h))
+        o_f, i_f = banks["fused"].attend(StepPlan(n_split=1, **dec), q.cuda(), k.cuda(), v.cuda())
+        o_s, i_s = banks["split"].attend(StepPlan(n_split=2, **dec), q.cuda(), k.cuda(), v.cuda())
+        assert torch.equal(i_f, i_s), i
+        assert torch.allclose(o_f.float(), o_s.float(), atol=1e-3, rtol=5e-4)
+    assert banks["fused"].extent == [idx + stride] * L
+    assert torch.equal(banks["fused"].slot_of_pos, banks["split"].slot_of_pos)
+    assert torch.equal(banks["fused"].score_sum, banks["split"].score_sum)
