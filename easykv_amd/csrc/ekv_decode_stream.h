@@ -26,8 +26,11 @@ struct EkvDecodeGeom {
 //
 // PHYS (fused kernel, t0 = 0, t1 = T): the rows are streamed in PHYSICAL order, 0 .. a.phys_extent-1, not through the slot
 // map.  Eviction recycles rows in place, so after a few thousand steps of a score-driven policy the birth order of the
-// live rows is a random permutation of their addresses; gathering 256-byte rows in that order costs 16-18 % of the
-// bandwidth (measured: 188 -> 223 us per launch after 4000 steps), while attention does not care about the order.
+// live rows is a random permutation of their addresses, while attention does not care about the order: streaming by
+// address keeps the HBM access pattern sequential whatever the eviction history was and takes the slot-map loads out of the
+// loop.  (Measured on MI355X at T = 2049, D = 128: gathering whole 256-byte rows in random order costs nothing measurable,
+// +-3 % run-to-run noise either way; the 188 -> 223 us drift of the first version over 1000+ steps was the roco select
+// falling through to its bisection fallback, see ekv_decode_tail.h.)
 // `s_dead` (LDS, one bit per row) marks free rows, the row the new token is being written to and the padding past the
 // extent; logits are stored at the PHYSICAL row index (the scorer tail reads them back through the slot map).
 template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4, bool PHYS = false>

@@ -230,3 +230,48 @@ def test_random_long_decode_runs(seed):
     finally:
         O.SELECT_HOOK = None
     assert bank.n_slots == [T0] * L
+
+
+@pytest.mark.parametrize("policy,D,rep", [("roco", 128, 1), ("roco", 64, 2), ("h2o_head", 32, 4)])
+def test_long_run_steady_state_decode_against_the_oracle(policy, D, rep):
+    """1200 evicting decode steps at a small fixed budget through the ONE-LAUNCH decode step (physical-order stream, histogram
+    select): long enough for the policy's steady state, where the lowest-mean tokens are exactly the ones outside roco's
+    feasible set and the slot map is a random permutation.  The oracle is re-seeded from the bank's own state before every
+    step (ordered K/V, score rows), so each of the 1200 x 8 decisions is checked on its own — a trajectory followed freely
+    is lost at its first unstable draw, after ~100 steps.  Every decision the probe calls well defined must match."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    L, H, budget, steps = 2, 4, 120, 1200
+    Hq, W = H * rep, budget + 1
+    g = torch.Generator().manual_seed(77 + D)
+    k0, v0 = _mk(L, H, budget, D, g), _mk(L, H, budget, D, g)
+    bank = KVBank(L, Hq, H, D, cap=budget + 9)
+    bank.load_rows(k0.cuda(), v0.cuda())
+    bank.state_init(W, 0)
+    kw = dict(policy=policy, phase="decode", evict=True, score_off=0, budget=budget)
+    assert bank.step_plan(StepPlan(n_split=1, **kw), 1) == (1, True)
+    verified = unstable = 0
+    probe = Probe()
+    O.SELECT_HOOK = probe
+    try:
+        for i in range(steps):
+            q, k, v = _mk(L, Hq, 1, D, g), _mk(L, H, 1, D, g), _mk(L, H, 1, D, g)
+            kord, vord = (t.float().cpu() for t in bank.ordered_kv())
+            rows = [t[:, :, :W].cpu().clone() for t in (bank.score_sum, bank.score_sq, bank.score_cnt)]
+            out, ids = bank.attend(StepPlan(n_split=1, **kw), q.cuda(), k.cuda(), v.cuda())
+            for l in range(L):
+                st = O.LayerState(k=kord[l:l + 1], v=vord[l:l + 1], s=rows[0][l], q=rows[1][l], c=rows[2][l])
+                o_ref, ids_ref = O.layer_step(st, q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw))
+                assert torch.allclose(out[l].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4), (i, l)
+                same = ids[l, :, 0].cpu().long() == ids_ref[:, 0]
+                ok = ~probe.last_unstable
+                assert bool(same[ok].all()), (i, l, policy, D, rep)
+                verified += int(ok.sum())
+                unstable += int((~ok).sum())
+    finally:
+        O.SELECT_HOOK = None
+    assert verified >= 0.9 * steps * L * H, f"only {verified} well-defined decisions ({unstable} unstable)"
+    m = bank.slot_of_pos.cpu().numpy()
+    for l in range(L):
+        for h in range(H):
+            assert np.array_equal(np.sort(m[l, h]), np.arange(bank.cap))
