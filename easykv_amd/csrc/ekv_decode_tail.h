@@ -123,9 +123,13 @@ __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, s
 template <int REP, int ITEMS, int NW = 4, bool PHYS = false>
 __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, int h, size_t head_row, int T, int off, int W,
                                                 float* s_logit, int t_pad, float* sS, float* sQ, float* sC, RedN<NW>& red,
-                                                uint32_t* s_hist, unsigned long long* s_list, int list_cap) {
+                                                uint32_t* s_hist, unsigned long long* s_list, int list_cap,
+                                                const float* part_max = nullptr, int n_part = 0, int part_stride = 0) {
   const int tid = threadIdx.x;
   constexpr int NT = 64 * NW;
+  // PHYS: cell[it] = physical row of position tid + it * NT (loaded once; also feeds the slot-map shift at the end)
+  int cell[PHYS ? ITEMS : 1];
+  bool have_cells = false;
   const bool roco = sc.policy == EKV_POLICY_ROCO;
   const bool scored = roco || sc.policy == EKV_POLICY_H2O_HEAD || sc.policy == EKV_POLICY_TOVA;
 #ifdef EKV_TAIL_PROFILE
@@ -141,29 +145,37 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
     // PHYS: cell of position j (this thread's columns j = tid + NT*it) and of position off + j, loaded together
     // (unconditional, clamped: predicated loads get serialised by hipcc)
     const int32_t* map_c = sc.slot_of_pos + head_row;
-    int cell[PHYS ? ITEMS : 1], cell_off[PHYS ? ITEMS : 1];
+    int cell_off[PHYS ? ITEMS : 1];
+    have_cells = PHYS;
     if (PHYS) {
 #pragma unroll
       for (int it = 0; it < ITEMS; ++it) cell[it] = map_c[min(tid + it * NT, T - 1)];
 #pragma unroll
       for (int it = 0; it < ITEMS; ++it) cell_off[it] = off == 0 ? cell[it] : map_c[min(off + tid + it * NT, T - 1)];
     }
-    if (PHYS) {
+    if (part_max != nullptr) {
+      // the row maximum is already known: the streaming loop kept a running max per wave (same floats, max is exact)
 #pragma unroll
-      for (int it = 0; it < ITEMS; ++it) {
-        if (tid + it * NT < T) {
+      for (int r = 0; r < REP; ++r)
+        for (int i = 0; i < n_part; ++i) mx[r] = fmaxf(mx[r], part_max[(size_t)(i * REP + r) * part_stride]);
+    } else {
+      if (PHYS) {
 #pragma unroll
-          for (int r = 0; r < REP; ++r) mx[r] = fmaxf(mx[r], s_logit[(size_t)r * t_pad + cell[it]]);
+        for (int it = 0; it < ITEMS; ++it) {
+          if (tid + it * NT < T) {
+#pragma unroll
+            for (int r = 0; r < REP; ++r) mx[r] = fmaxf(mx[r], s_logit[(size_t)r * t_pad + cell[it]]);
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int j = tid; j < T; j += NT) {
+#pragma unroll
+          for (int r = 0; r < REP; ++r) mx[r] = fmaxf(mx[r], s_logit[(size_t)r * t_pad + j]);
         }
       }
-    } else {
-#pragma unroll 4
-      for (int j = tid; j < T; j += NT) {
-#pragma unroll
-        for (int r = 0; r < REP; ++r) mx[r] = fmaxf(mx[r], s_logit[(size_t)r * t_pad + j]);
-      }
+      red.template max_n<REP>(mx);
     }
-    red.template max_n<REP>(mx);
     if (PHYS) {
 #pragma unroll
       for (int it = 0; it < ITEMS; ++it) {
@@ -392,17 +404,26 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
     // read everything that moves, barrier, then write (the row belongs to this workgroup only)
     const int pv = off + victim;
     int32_t* map = sc.slot_of_pos + head_row;
-    int moved[ITEMS + 1];
+    if (PHYS && have_cells) {
+      // every thread still holds the map entries of its positions: nothing to read, no barrier
 #pragma unroll
-    for (int it = 0; it <= ITEMS; ++it) {
-      const int p = pv + tid + it * NT;
-      moved[it] = map[min(p, T - 1)];   // unconditional (clamped): predicated loads get serialised by hipcc
-    }
-    __syncthreads();
+      for (int it = 0; it < ITEMS; ++it) {
+        const int p = tid + it * NT;
+        if (p >= pv && p < T) map[p == pv ? T - 1 : p - 1] = cell[it];
+      }
+    } else {
+      int moved[ITEMS + 1];
 #pragma unroll
-    for (int it = 0; it <= ITEMS; ++it) {
-      const int p = pv + tid + it * NT;
-      if (p < T) map[p == pv ? T - 1 : p - 1] = moved[it];
+      for (int it = 0; it <= ITEMS; ++it) {
+        const int p = pv + tid + it * NT;
+        moved[it] = map[min(p, T - 1)];   // unconditional (clamped): predicated loads get serialised by hipcc
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it <= ITEMS; ++it) {
+        const int p = pv + tid + it * NT;
+        if (p < T) map[p == pv ? T - 1 : p - 1] = moved[it];
+      }
     }
   }
 }
