@@ -235,7 +235,7 @@ def main():
     if args.split_kernels:
         fused = False
 
-    def step(i, timed_idx=None):
+    def step(i, timed_idx=None, handoff=True):
         for l0 in range(0, L, lpl):
             lc = min(lpl, L - l0)
             a = (plan, qs[i, l0:l0 + lc], ks[i, l0:l0 + lc], vs[i, l0:l0 + lc])
@@ -260,7 +260,7 @@ def main():
                 bank.attend(*a, overlap_scorer=args.overlap_scorer, **kw)
         if args.overlap_scorer and args.graph:
             bank.join()        # a captured step must end with every forked stream joined
-        if world > 1 and not args.no_handoff and not args.graph:   # pipeline hand-off of the stage output (north star):
+        if handoff and world > 1 and not args.no_handoff and not args.graph:   # pipeline hand-off of the stage output (north star):
             # posted after this step's kernels, waited for at the next step, so the 8 KB transfer overlaps the next launch
             pending[:] = DS.ring_handoff_async(hidden, hidden_in, shard, pending)
 
@@ -273,7 +273,7 @@ def main():
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < args.prewarm_s:
             for _ in range(16):
-                step(n_pre % n_total)
+                step(n_pre % n_total, handoff=False)     # rank-local: the ranks run different numbers of pre-warm steps
                 n_pre += 1
             torch.cuda.synchronize()
     for i in range(args.warmup):
