@@ -135,6 +135,11 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
       ekv_decode_fused_supported(bank->head_dim, rep, T, w.t_pad, ekv_fused_logit_pad(bank, st, w.t_pad), st->n_evict, bank->cap, 8)) {
     n_split = 1;   // >= 1 head per CU: one 8-wave workgroup per head beats key-range splits + a second kernel (GQA shapes)
   }
+  if (n_split <= 0 && st->q_len > 1 && qpw <= 2 && w.n_qblocks == 1 && st->layer_count * bank->n_kv_heads >= 1024) {
+    // >= 4 heads per CU: unsplit heads fill the chip (measured at C2 / stride 16: no slower than 3 splits even with a separate
+    // scorer, because the fold moves into the kernel) and the scorer can then run as the tail of the attention kernel
+    n_split = 1;
+  }
   if (n_split <= 0) {
     const int wgs = st->layer_count * bank->n_kv_heads * w.n_qblocks;
     // decode: >= 1024 workgroups (4 per CU, one round).  chunk kernels hold 3 (QPW=1) or 2 workgroups per CU: a grid of
@@ -346,16 +351,23 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   const int ph = st->phases;
   if (ph < 0 || ph > 15 || ((ph & 2) && (ph & (4 | 8)))) return EKV_E_ARG;
   hipError_t err = hipSuccess;
+  // Whole chunk step in ONE launch: unsplit heads (the kernel folds its own output), one-pass logits, a scored policy, and the
+  // scorer's LDS rows fit next to two workgroups per CU.  The scorer of a head then runs as the tail of the workgroup that
+  // streamed it and overlaps the K/V stream of the workgroups still running (tova_head_mean needs all heads of a layer first).
+  const bool fuse_chunk = n > 1 && ph == 0 && ws.fold_in_kernel && !ws.two_pass && scored && ws.n_qblocks == 1 &&
+                          rep * n <= 64 && !(st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) &&
+                          ekv_score_lds_bytes_nt256(sa) <= 64 * 1024 && st->n_split != -1;
+  if (fuse_chunk) sa.skip_fold = 1;
   if (ph != 0 && !(ph & 1)) {
   } else if (n == 1) {
     if (!ekv_attn_decode_supported(bank->head_dim, rep)) return EKV_E_UNSUPPORTED;
     err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
   } else {
     if (!ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
-    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, ws.two_pass != 0, s);
+    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, ws.two_pass != 0, s, fuse_chunk ? &sa : nullptr);
   }
   if (err != hipSuccess) return EKV_E_LAUNCH;
-  if (ph == 1) return EKV_OK;
+  if (ph == 1 || fuse_chunk) return EKV_OK;
 
   if ((ph & 4) || (!scored && st->n_evict == 0 && !(ph & 8))) {
     // nothing to score and nothing to evict ('full', or any unknown policy string): the step is the partial fold only,

@@ -2,7 +2,7 @@
 #include "ekv_common.h"
 #include "ekv_kernels.h"
 
-#define EKV_DECL(d, m) hipError_t ekv_launch_attn_chunk_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t);
+#define EKV_DECL(d, m) hipError_t ekv_launch_attn_chunk_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t, const EkvScoreArgs*);
 EKV_DECL(32, 0) EKV_DECL(32, 1) EKV_DECL(32, 2) EKV_DECL(64, 0) EKV_DECL(64, 1) EKV_DECL(64, 2)
 EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 #undef EKV_DECL
@@ -53,7 +53,10 @@ __global__ void __launch_bounds__(128) ekv_rope_q_kernel(const EkvAttnArgs a, in
   }
 }
 
-hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s) {
+// fuse_sc != nullptr: one-pass step with unsplit heads whose scorer runs as the tail of the attention kernel (no second launch)
+hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
+                                 const EkvScoreArgs* fuse_sc) {
+  if (two_pass && fuse_sc != nullptr) return hipErrorInvalidValue;
   if (a.rope_cos != nullptr) {
     if (a.q_rot_hi == nullptr || a.q_rot_lo == nullptr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ekv_rope_q_kernel, dim3(a.n_q_heads * a.q_len, layer_count), dim3(128), 0, s, a, head_dim);
@@ -62,7 +65,7 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
   if (qb_rows != a.qb_rows || n_qblocks != a.n_qblocks) return hipErrorInvalidValue;
   if (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts != (qpw == 4 ? 4 : 2) * n_qblocks)) return hipErrorInvalidValue;
-#define EKV_GO(d, m) ekv_launch_attn_chunk_d##d##_m##m(a, qpw, layer_count, s)
+#define EKV_GO(d, m) ekv_launch_attn_chunk_d##d##_m##m(a, qpw, layer_count, s, fuse_sc)
   hipError_t e = hipSuccess;
   switch (head_dim) {
     case 32: e = two_pass ? EKV_GO(32, 1) : EKV_GO(32, 0); if (two_pass && e == hipSuccess) e = EKV_GO(32, 2); break;

@@ -42,6 +42,17 @@ for c in range(n_chunks):
     e0.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4],phases=1); e1.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4],phases=2); e2.record()
     ev.append((e0,e1,e2))
 torch.cuda.synchronize(); t_chunks=time.perf_counter()-t0
+# whole step as the library runs it (phases=0: ONE launch when the scorer fuses into the attention kernel)
+ev0=[]
+for c in range(40):
+    plan=StepPlan(streaming=STREAM,policy=POLICY,phase='prefill',accumulate=True,evict=not NOEVICT,budget=bp,recent=recent,sink=sink,stride=stride,tova_head_mean=True,n_split=NSPLIT)
+    if NOEVICT: break
+    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+    e0.record(); bank.attend(plan,qs[c%4],ks[c%4],vs[c%4]); e1.record(); ev0.append((e0,e1))
+torch.cuda.synchronize()
+if ev0:
+    tw=sum(a.elapsed_time(b) for a,b in ev0[4:])/len(ev0[4:])*1e3
+    print(f"whole step, phases=0 (n_split,fused-plan)={bank.step_plan(plan,stride)}: {tw:.1f} us -> {stride/tw*1e6:.0f} prefill tok/s")
 ta=sum(a.elapsed_time(b) for a,b,_ in ev[2:])/len(ev[2:])*1e3; ts=sum(b.elapsed_time(c) for _,b,c in ev[2:])/len(ev[2:])*1e3
 T=idx+stride
 bytes_attn = L*(2*H*T*D*2 + 2*Hq*stride*D*2 + 2*H*stride*D*2)
