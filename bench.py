@@ -114,7 +114,7 @@ def event_overhead_us(dev, reps=32):
     return v[len(v) // 2]
 
 
-def strided_prefill(args, dev, n_chunks=24, warm=4):
+def strided_prefill(args, dev, n_chunks=48, warm=8):
     """Secondary figure (never `value`): BASELINE.json configs[1] — the chunk phase of a strided prefill, S=4096, stride 8,
     budget 0.5, kv_policy roco (SURVEY.md §8d Bench-P): the cache oscillates idx <-> idx+stride, every chunk step attends
     the retained slots with 8 queries per head, scores and evicts 8 slots per (layer, head); all layers in one launch pair."""
@@ -130,27 +130,30 @@ def strided_prefill(args, dev, n_chunks=24, warm=4):
     if not args.identity_layout:                      # steady state of the chunk phase: rows recycled in place for many steps
         bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=g, device=dev), dim=-1).int()
     bank.state_init(idx + stride, 2, stride)
-    q, k, v = rnd(Hq, stride), rnd(H, stride), rnd(H, stride)
+    # distinct inputs per step: re-using one chunk would append the same eight key rows over and over, whose identical scores
+    # pile up as exact ties in the selection keys (an artefact no real prompt produces)
+    n_in = 2 * warm + n_chunks + 8
+    qs_, ks_, vs_ = [rnd(Hq, stride) for _ in range(n_in)], [rnd(H, stride) for _ in range(n_in)], [rnd(H, stride) for _ in range(n_in)]
     plan = StepPlan(policy=args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco", phase="prefill", accumulate=True, evict=True,
                     budget=bp, recent=int(bp * 0.1), sink=4, stride=stride, tova_head_mean=True)
     out = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
     ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
     # whole step as the library runs it (phases = 0: one launch when the scorer fuses into the attention kernel) ...
-    ev = []
+    # (one HIP-event pair around the timed region: a pair per step costs ~8 us of marker latency, see event_overhead_us)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for i in range(warm + n_chunks):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        e[0].record()
-        bank.attend(plan, q, k, v, out=out, evict_ids=ids)
-        e[1].record()
-        if i >= warm:
-            ev.append(e)
+        if i == warm:
+            ev[0].record()
+        bank.attend(plan, qs_[i], ks_[i], vs_[i], out=out, evict_ids=ids)
+    ev[1].record()
     torch.cuda.synchronize(dev)
-    t_step = sum(a.elapsed_time(b) for a, b in ev) / len(ev) * 1e-3
+    t_step = ev[0].elapsed_time(ev[1]) / n_chunks * 1e-3
     one_launch = bool(bank.step_plan(plan, stride)[0] == 1)
     # ... and the same step as two launches (attention kernel, then fold + score + select + compaction), for the breakdown
     ev2 = []
     for i in range(warm + 8):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        q, k, v = qs_[warm + n_chunks + i], ks_[warm + n_chunks + i], vs_[warm + n_chunks + i]
         e[0].record()
         bank.attend(plan, q, k, v, out=out, evict_ids=ids, phases=1)     # chunk attention kernel
         e[1].record()
@@ -169,7 +172,7 @@ def strided_prefill(args, dev, n_chunks=24, warm=4):
             "us_per_chunk_step": t_step * 1e6, "one_launch_fused_scorer": one_launch,
             "as_two_launches_us": {"attn_kernel": t_attn * 1e6, "score_select": t_score * 1e6},
             "algorithmic_bytes_per_step": by["total"] * L, "achieved_gbs": by["total"] * L / t_step / 1e9,
-            "frac_of_hbm_peak": by["total"] * L / t_step / 1e9 / HBM_PEAK_GBS, "chunk_steps_timed": len(ev),
+            "frac_of_hbm_peak": by["total"] * L / t_step / 1e9 / HBM_PEAK_GBS, "chunk_steps_timed": n_chunks,
             "slot_map": "identity" if args.identity_layout else "scattered"}
 
 
