@@ -256,7 +256,9 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                         raise UnboundLocalError("auto mode + kv_policy='random' is broken in the reference (easykv/easykv.py:744)")
                     plan.range_start = sink
                 else:                                           # :343-362: oldest / uniformly random generated slot
-                    e = 0 if policy == "recency" else int(torch.randint(len(positions), (1,)))
+                    # 'random': the reference's own draw — argmax of torch.rand over the generated slots, CPU generator
+                    # (easykv/easykv.py:354-356), so a run seeded like a reference run evicts the same slots
+                    e = 0 if policy == "recency" else int(torch.topk(torch.rand(len(positions)), k=1, dim=-1)[1][0])
                     positions.pop(e)
                     plan.range_start = score_off + e
             # steady state (same plan, same cache length as the step before, one slot evicted per step): replay the graph
@@ -291,8 +293,10 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                             tova_head_mean=tova_head_mean)
             if plan.evict and policy == "recency":
                 plan.range_start = sink                          # :491-493
-            elif plan.evict and policy == "random":              # :494-499
-                plan.range_start = int(torch.randint(idx, (1,)))
+            elif plan.evict and policy == "random":              # :494-499: argmax of torch.rand over the row, chunk excluded
+                draw = torch.rand(idx + stride)
+                draw[-stride:] = -1e9
+                plan.range_start = int(torch.topk(draw, k=1, dim=-1)[1][0])
             out = forward(cache, input_ids[:, tok_i:tok_i + stride], list(range(cur_pos, cur_pos + stride)), plan)
             logits_last = out.logits[:, -1, :]
             if keep_logits:
