@@ -8,6 +8,8 @@ size_t ekv_score_lds_bytes_nt512(const EkvScoreArgs&);
 hipError_t ekv_launch_score_select_nt256(const EkvScoreArgs&, int, hipStream_t);
 hipError_t ekv_launch_score_select_nt512(const EkvScoreArgs&, int, hipStream_t);
 hipError_t ekv_launch_tova_headmean_nt512(const EkvScoreArgs&, int, hipStream_t);
+size_t ekv_score_lds_bytes_nt1024(const EkvScoreArgs&);
+hipError_t ekv_launch_score_select_nt1024(const EkvScoreArgs&, int, hipStream_t);
 
 size_t ekv_score_lds_bytes(const EkvScoreArgs& a) { return ekv_score_lds_bytes_nt512(a); }
 
@@ -15,7 +17,12 @@ hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipSt
   // 256 threads only while at least three such workgroups fit a CU's LDS; wide score rows (C4: W = 5098 -> 82 KB) leave
   // room for one workgroup per CU, which must then bring 512 threads
   const bool small_blocks = a.n_kv_heads * layer_count >= 768 && ekv_score_lds_bytes_nt256(a) <= 53 * 1024;
-  return small_blocks ? ekv_launch_score_select_nt256(a, layer_count, s) : ekv_launch_score_select_nt512(a, layer_count, s);
+  if (small_blocks) return ekv_launch_score_select_nt256(a, layer_count, s);
+  // one workgroup per CU either way (at most one (head, layer) pair per CU, or LDS rows too wide for two): give it all 16
+  // wave slots — the logits sweep is VALU-bound on exact expf / IEEE div and 2 waves per SIMD do not fill the pipeline
+  const bool one_per_cu = a.n_kv_heads * layer_count <= 256 || ekv_score_lds_bytes_nt512(a) > 80 * 1024;
+  if (one_per_cu && ekv_score_lds_bytes_nt1024(a) <= 160 * 1024) return ekv_launch_score_select_nt1024(a, layer_count, s);
+  return ekv_launch_score_select_nt512(a, layer_count, s);
 }
 
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s) {
