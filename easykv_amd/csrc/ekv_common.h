@@ -111,4 +111,11 @@ __device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split,
   return ekv_fold_partials<BATCH>(p0, n_split, PS, d, mm, ls);
 }
 
+// Smallest batch that covers the partials in one round trip (up to 32).  Masked entries of a batch add exact zeros, so the
+// result does not depend on the choice as long as n_split <= BATCH; a 32-wide batch over 8 partials only wastes 24 clamped loads.
+__device__ __forceinline__ float ekv_fold_partials_auto(const float* p0, int n_split, int PS, int d) {
+  return n_split <= 8 ? ekv_fold_partials<8>(p0, n_split, PS, d)
+                      : (n_split <= 16 ? ekv_fold_partials<16>(p0, n_split, PS, d) : ekv_fold_partials<32>(p0, n_split, PS, d));
+}
+
 static inline __host__ __device__ size_t ekv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(kSNT) ekv_decode_score_kernel(const EkvScoreAr
   const int PS = D + 2;
   for (int idx = tid; idx < (sc.skip_fold ? 0 : REP * D); idx += kSNT) {
     const int r = idx / D, d = idx % D;
-    sc.out[(hq0 + r) * D + d] = __float2half(ekv_fold_partials(sc.partials + ((hq0 + r) * sc.n_split) * PS, sc.n_split, PS, d));
+    sc.out[(hq0 + r) * D + d] = __float2half(ekv_fold_partials_auto(sc.partials + ((hq0 + r) * sc.n_split) * PS, sc.n_split, PS, d));
   }
   __syncthreads();   // LDS-DMA complete (vmcnt(0) before the barrier) and visible
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(red.buf + 2 * kSNW * 8);     // roco select scratch: histogram, candidate list
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(128) ekv_fold_kernel(const EkvScoreArgs sc) {
   const int D = sc.head_dim, PS = D + 2;
   const size_t row = (size_t)blockIdx.y * sc.n_q_heads * sc.q_len + blockIdx.x;
   const float* p0 = sc.partials + row * sc.n_split * PS;
-  for (int d = threadIdx.x; d < D; d += 128) sc.out[row * D + d] = __float2half(ekv_fold_partials(p0, sc.n_split, PS, d));
+  for (int d = threadIdx.x; d < D; d += 128) sc.out[row * D + d] = __float2half(ekv_fold_partials_auto(p0, sc.n_split, PS, d));
 }
 
 size_t score_lds(int rep, int t_pad, int policy) {
