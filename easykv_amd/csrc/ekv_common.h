@@ -111,11 +111,20 @@ __device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split,
   return ekv_fold_partials<BATCH>(p0, n_split, PS, d, mm, ls);
 }
 
-// Smallest batch that covers the partials in one round trip (up to 32).  Masked entries of a batch add exact zeros, so the
-// result does not depend on the choice as long as n_split <= BATCH; a 32-wide batch over 8 partials only wastes 24 clamped loads.
+// Batch = loads issued together per round trip.  Masked entries of a batch add exact zeros, so any batch that covers all
+// partials gives the same result; a batch much wider than n_split only wastes clamped loads (C3: 32-wide batches over 8
+// partials were 65 % of its scorer).  Batches are capped at 16 (8 for 1024-thread blocks): a 32-wide batch keeps 96 values live,
+// and under a 512-thread launch bound (128 VGPRs) hipcc then serialises it into one exposed round trip PER SPLIT — 17 of them,
+// 8.5 of the 19 us of the per-layer decode scorer.
+template <int MAXB = 16>
+__device__ __forceinline__ float ekv_fold_partials_auto(const float* p0, int n_split, int PS, int d, float& mm, float& ls) {
+  if (MAXB <= 8 || n_split <= 8) return ekv_fold_partials<8>(p0, n_split, PS, d, mm, ls);
+  return ekv_fold_partials<16>(p0, n_split, PS, d, mm, ls);
+}
+template <int MAXB = 16>
 __device__ __forceinline__ float ekv_fold_partials_auto(const float* p0, int n_split, int PS, int d) {
-  return n_split <= 8 ? ekv_fold_partials<8>(p0, n_split, PS, d)
-                      : (n_split <= 16 ? ekv_fold_partials<16>(p0, n_split, PS, d) : ekv_fold_partials<32>(p0, n_split, PS, d));
+  float mm, ls;
+  return ekv_fold_partials_auto<MAXB>(p0, n_split, PS, d, mm, ls);
 }
 
 static inline __host__ __device__ size_t ekv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -2,6 +2,9 @@
 // Folds the key-range-split partials of ekv_attn_decode_kernel into the fp16 output, pulls the exported logits and
 // the score rows into LDS by LDS-DMA and runs the same scorer tail as the fused kernel (ekv_decode_tail.h).
 // Used when layers are launched one at a time (heads must be split to fill the chip).
+#ifdef EKV_TAIL_PROFILE
+#define EKV_STAMP(i) do { if (threadIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
+#endif
 #include "ekv_decode_tail.h"
 
 namespace {
@@ -34,6 +37,10 @@ __global__ void __launch_bounds__(kSNT) ekv_decode_score_kernel(const EkvScoreAr
   const size_t head_row = ((size_t)(sc.layer_begin + ll) * sc.n_kv_heads + h) * sc.cap;
   const size_t hq0 = (size_t)ll * sc.n_q_heads + (size_t)h * REP;
 
+#ifdef EKV_TAIL_PROFILE
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sc.tova_row) + ((size_t)ll * sc.n_kv_heads + h) * 8;
+#endif
+  EKV_STAMP(0);
   if (scored) ekv_tail_prefetch_rows<kSNW>(sc, head_row, W, w_pad, roco, sS, sQ, sC);
   if (scored && sc.accumulate) {   // logits rows -> LDS (rows are 256-byte aligned in the workspace)
     const int full = t_pad / 256;
@@ -53,6 +60,7 @@ __global__ void __launch_bounds__(kSNT) ekv_decode_score_kernel(const EkvScoreAr
     sc.out[(hq0 + r) * D + d] = __float2half(ekv_fold_partials_auto(sc.partials + ((hq0 + r) * sc.n_split) * PS, sc.n_split, PS, d));
   }
   __syncthreads();   // LDS-DMA complete (vmcnt(0) before the barrier) and visible
+  EKV_STAMP(1);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(red.buf + 2 * kSNW * 8);     // roco select scratch: histogram, candidate list
   unsigned long long* s_list = reinterpret_cast<unsigned long long*>(s_hist + 264);
   ekv_decode_tail<REP, ITEMS, kSNW>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red, s_hist, s_list, kSNT);
@@ -83,7 +91,9 @@ hipError_t launch_k(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
 
 template <int REP>
 hipError_t launch_rep(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
-  return sc.n_slots <= kSNT * (2304 / kSNT) ? launch_k<REP, 2304 / kSNT>(sc, layer_count, s) : launch_k<REP, 6144 / kSNT>(sc, layer_count, s);
+  // ITEMS = ceil(row width / threads) (a floor here sent T = 2049 to the 6144-wide build: 12 items per thread instead of 5)
+  constexpr int I0 = (2304 + kSNT - 1) / kSNT, I1 = (6144 + kSNT - 1) / kSNT;
+  return sc.n_slots <= kSNT * I0 ? launch_k<REP, I0>(sc, layer_count, s) : launch_k<REP, I1>(sc, layer_count, s);
 }
 
 }  // namespace
