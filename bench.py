@@ -402,7 +402,7 @@ def main():
                                      "score_select_us": t_score * 1e6}
         if world == 1 and not args.no_prefill and not args.graph:
             line["strided_prefill"] = strided_prefill(args, dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args, budget, args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco")
         print(json.dumps(line))
     if world > 1:
