@@ -119,7 +119,8 @@ __device__ __forceinline__ float ekv_fold_partials(const float* p0, int n_split,
 template <int MAXB = 16>
 __device__ __forceinline__ float ekv_fold_partials_auto(const float* p0, int n_split, int PS, int d, float& mm, float& ls) {
   if (MAXB <= 8 || n_split <= 8) return ekv_fold_partials<8>(p0, n_split, PS, d, mm, ls);
-  return ekv_fold_partials<16>(p0, n_split, PS, d, mm, ls);
+  if (n_split <= 16 || n_split > 24) return ekv_fold_partials<16>(p0, n_split, PS, d, mm, ls);
+  return ekv_fold_partials<24>(p0, n_split, PS, d, mm, ls);   // 17..24 partials (decode, T ~ 2k: 17 splits) in ONE round trip
 }
 template <int MAXB = 16>
 __device__ __forceinline__ float ekv_fold_partials_auto(const float* p0, int n_split, int PS, int d) {
