@@ -275,3 +275,74 @@ def test_long_run_steady_state_decode_against_the_oracle(policy, D, rep):
     for l in range(L):
         for h in range(H):
             assert np.array_equal(np.sort(m[l, h]), np.arange(bank.cap))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_one_launch_chunk_step_equals_two_launches_and_the_oracle(seed):
+    """Unsplit heads + a scored policy + <= 64 folded rows: the scorer runs as the tail of the chunk attention kernel (one launch).
+    Same trajectory as the two-launch form (attention kernel, then the stand-alone scorer kernel: phases 1 and 2) — bit-identical
+    score rows, slot maps and evicted sets — and as the oracle; D, GQA factor, stride, policy, RoPE-on-read and a non-evicting
+    first step (keep_attention style) are drawn at random."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    rng = np.random.default_rng(4000 + seed)
+    D = int(rng.choice([32, 64, 128]))
+    H = int(rng.choice([1, 2, 4]))
+    rep = int(rng.choice([1, 2, 4, 8]))
+    s = int(rng.choice([c for c in (2, 4, 8, 16, 24, 32, 64) if c * rep <= 64]))
+    Hq = H * rep
+    idx = int(rng.integers(150, 700))
+    policy = str(rng.choice(["roco", "h2o_head", "tova"]))
+    stream = bool(rng.integers(0, 2))
+    L = 3
+    budget_p, recent, sink = idx + int(rng.integers(0, s)), int(idx * 0.2), 4
+    g = torch.Generator().manual_seed(40 + seed)
+    # keep: keep_attention-style run — counts of easykv.py:412 (c = idx - j), a scored step that does not evict brings the cache
+    # from idx - s to idx, then evicting steps.  Otherwise the plain encoding rules: idx slots, every step evicts.
+    keep = bool(seed % 2)
+    t_prev = idx - s if keep else idx
+    k0, v0 = _mk(L, H, t_prev, D, g), _mk(L, H, t_prev, D, g)
+    cos = sin = None
+    if stream:
+        cos, sin = O.rope_tables(idx + s + 8, D)
+    banks = {}
+    for name in ("one", "two"):
+        b = KVBank(L, Hq, H, D, cap=idx + s)
+        if stream:
+            b.set_rope(cos, sin)
+        b.load_rows(k0.cuda(), v0.cuda())
+        b.state_init(idx + s, 1 if keep else 2, s)
+        banks[name] = b
+    st = O.LayerState(k=k0[:1].float(), v=v0[:1].float())
+    st.s, st.q, st.c = O.init_state_prefill((H,), idx, s, False)
+    if keep:
+        st.c = (torch.arange(idx + s, 0, -1, dtype=torch.float32) - float(s)).expand(H, idx + s).clone()
+    probe = Probe()
+    O.SELECT_HOOK = probe
+    follow = True
+    try:
+        for step in range(5):
+            q, k, v = _mk(L, Hq, s, D, g), _mk(L, H, s, D, g), _mk(L, H, s, D, g)
+            kw = dict(policy=policy, phase="prefill", accumulate=True, evict=step > 0 or not keep, budget=budget_p, recent=recent, sink=sink,
+                      stride=s, tova_head_mean=False, streaming=stream)
+            o1, i1 = banks["one"].attend(StepPlan(n_split=1, **kw), q.cuda(), k.cuda(), v.cuda())
+            o2 = torch.empty_like(o1)
+            i2 = torch.empty_like(i1) if i1 is not None else None
+            banks["two"].attend(StepPlan(n_split=1, **kw), q.cuda(), k.cuda(), v.cuda(), out=o2, evict_ids=i2, phases=1)
+            banks["two"].attend(StepPlan(n_split=1, **kw), q.cuda(), k.cuda(), v.cuda(), out=o2, evict_ids=i2, phases=2)
+            assert torch.equal(o1, o2), (seed, step)
+            if i1 is not None:
+                assert torch.equal(i1, i2), (seed, step)
+            assert torch.equal(banks["one"].score_sum, banks["two"].score_sum)
+            assert torch.equal(banks["one"].slot_of_pos, banks["two"].slot_of_pos)
+            if follow:
+                o_ref, ids_ref = O.layer_step(st, q[:1].float(), k[:1].float(), v[:1].float(), O.StepPlan(**kw), cos, sin)
+                assert torch.allclose(o1[0].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4), (seed, step, D, H, rep, s, stream)
+                if kw["evict"]:
+                    got, ref = torch.sort(i1[0].cpu().long(), dim=-1)[0], torch.sort(ids_ref, dim=-1)[0]
+                    ok = ~probe.last_unstable
+                    assert bool((got == ref).all(dim=-1)[ok].all()), (seed, step, D, H, rep, s, policy, stream, keep)
+                    follow = bool(ok.all())
+    finally:
+        O.SELECT_HOOK = None
+    assert banks["one"].n_slots == [idx] * L
