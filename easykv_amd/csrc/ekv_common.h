@@ -128,4 +128,12 @@ __device__ __forceinline__ float ekv_fold_partials_auto(const float* p0, int n_s
   return ekv_fold_partials_auto<MAXB>(p0, n_split, PS, d, mm, ls);
 }
 
+// Barrier that only orders LDS traffic: global loads of the next super-tile stay in flight across it
+// (__syncthreads() would drain vmcnt(0) whenever a global store may be pending).
+__device__ __forceinline__ void ekv_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 static inline __host__ __device__ size_t ekv_align(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -33,11 +33,17 @@ struct EkvDecodeGeom {
 // falling through to its bisection fallback, see ekv_decode_tail.h.)
 // `s_dead` (LDS, one bit per row) marks free rows, the row the new token is being written to and the padding past the
 // extent; logits are stored at the PHYSICAL row index (the scorer tail reads them back through the slot map).
-template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4, bool PHYS = false>
+// `mask_ready` (PHYS): finishes the dead-row bits (LDS barriers inside, so every wave calls it exactly once).  It runs after
+// the loads of the wave's FIRST iteration have been issued — the K/V addresses do not depend on it — so the round trip of the
+// free list hides behind the first K/V round trip instead of preceding it.
+struct EkvNoop {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4, bool PHYS = false, typename MaskReady = EkvNoop>
 __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
                                                   int logit_stride, int t0, int t1_in, int ll, int h, size_t head_row,
                                                   float (&m)[REP], float (&l)[REP], float (&o)[REP][8],
-                                                  const uint8_t* s_dead = nullptr) {
+                                                  const uint8_t* s_dead = nullptr, MaskReady mask_ready = MaskReady()) {
   using Gm = EkvDecodeGeom<D, NW>;
   constexpr int LPR = Gm::LPR, RW = Gm::RW;
   constexpr int kNW = NW;
@@ -91,12 +97,6 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   const __half* k_new_row = a.k_new + ((size_t)ll * a.n_kv_heads + h) * D;
   const __half* v_new_row = a.v_new + ((size_t)ll * a.n_kv_heads + h) * D;
   const int slot_base = SLOT_LDS ? t0 : 0;   // index origin of s_slot
-  if (t_new >= t0 && t_new < t1 && wave == 0 && grp == 0) {  // append: the new row goes into the recycled slot
-    const size_t off = (head_row + s_slot[t_new - slot_base]) * D;
-    reinterpret_cast<uint4*>(a.k_w + off)[sub] = reinterpret_cast<const uint4*>(k_new_row)[sub];
-    reinterpret_cast<uint4*>(a.v_w + off)[sub] = reinterpret_cast<const uint4*>(v_new_row)[sub];
-  }
-
 #pragma unroll
   for (int r = 0; r < REP; ++r) {
     m[r] = EKV_NEG_INF;
@@ -105,13 +105,20 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     for (int i = 0; i < 8; ++i) o[r][i] = 0.f;
   }
 
-  // The appended row is peeled off the loop: its K/V come from k_new/v_new, one lane group scores it here, and the loop
-  // covers [t0, t_new) — with T = budget + 1 = 2049 that is exactly 16 full iterations instead of 17.
+  // The appended row is peeled off the loop: its K/V come from k_new / v_new and one lane group appends and scores it AFTER
+  // the loop (below) — doing that first cost wave 0 three dependent round trips (slot index, k_new, v_new -> store) before
+  // its first K/V load, while the other waves were already streaming.  The loop covers [t0, t_new): with T = budget + 1 =
+  // 2049 that is exactly 16 full iterations instead of 17.
   const bool has_new = t_new >= t0 && t_new < t1;
   if (has_new) t1 = t_new;
-  if (has_new && wave == 0 && grp == 0) {
+  auto appended_row = [&]() {
+    if (!(has_new && wave == 0 && grp == 0)) return;
+    const int slot_new = s_slot[t_new - slot_base];
     const uint4 kn = reinterpret_cast<const uint4*>(k_new_row)[sub];
     const uint4 vn = reinterpret_cast<const uint4*>(v_new_row)[sub];
+    const size_t off = (head_row + slot_new) * D;          // append: the new row goes into the recycled slot
+    reinterpret_cast<uint4*>(a.k_w + off)[sub] = kn;
+    reinterpret_cast<uint4*>(a.v_w + off)[sub] = vn;
     float kpn[8];
     if (ROPE) rope_key(kn, t_new, kpn);
 #pragma unroll
@@ -125,13 +132,22 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         acc = ekv_dot8(qv[r], kn, 0.f);
       }
       acc = ekv_group_sum<LPR>(acc) / a.sm_div;
-      if (logit_out != nullptr && sub == 0) logit_out[(size_t)r * logit_stride + (PHYS ? s_slot[t_new] : t_new)] = acc;
-      m[r] = acc;      // p = exp(acc - m) = 1
-      l[r] = 1.f;
-      ekv_axpy8(1.f, vn, o[r]);
+      if (logit_out != nullptr && sub == 0) logit_out[(size_t)r * logit_stride + (PHYS ? slot_new : t_new)] = acc;
+      // one more row for this lane group's online softmax
+      const float mn = fmaxf(m[r], acc);
+      const float alpha = m[r] == EKV_NEG_INF ? 0.f : exp2f((m[r] - mn) * EKV_LOG2E);
+      const float p = exp2f((acc - mn) * EKV_LOG2E);
+      l[r] = l[r] * alpha + p;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[r][i] *= alpha;
+      ekv_axpy8(p, vn, o[r]);
+      m[r] = mn;
     }
+  };
+  if (!PHYS && t1 <= t0) {   // the split held only the appended row
+    appended_row();
+    return;
   }
-  if (!PHYS && t1 <= t0) return;   // the split held only the appended row
 
   static_assert(kU == 8, "index prefetch assumes 8 rows per lane group");
   if (PHYS) t1 = a.phys_extent;   // loop bound: physical rows [0, E); which of them count is s_dead's business
@@ -143,7 +159,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     ia = ip[0];
     ib = ip[1];
   }
-  for (int base = t0 + wave * RW; base < t1; base += kNW * RW) {
+  auto iteration = [&](const int base, auto&& after_issue) {
     uint4 kr[kU], vr[kU];
     const int j0 = base + grp * kU;
     const int cur[8] = {(int)ia.x, (int)ia.y, (int)ia.z, (int)ia.w, (int)ib.x, (int)ib.y, (int)ib.z, (int)ib.w};
@@ -164,6 +180,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
       kr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(kp) + sub));
       vr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(vp) + sub));
     }
+    after_issue();
     // PHYS: bit u of dead8 = row j0+u is free / being appended / past the extent (j0 is a multiple of 8: one mask byte)
     const unsigned dead8 = PHYS ? s_dead[j0 >> 3] : 0u;
     if (PHYS && dead8 != 0u) {   // rare: a dead row may hold anything (0 * inf = NaN in the PV accumulation)
@@ -229,7 +246,18 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
       }
       m[r] = mn;
     }
+  };
+  int base = t0 + wave * RW;
+  if (PHYS) {
+    if (t1 > (kNW - 1) * RW) {   // every wave has a first iteration: peel it around the mask completion
+      iteration(base, mask_ready);
+      base += kNW * RW;
+    } else {
+      mask_ready();
+    }
   }
+  for (; base < t1; base += kNW * RW) iteration(base, EkvNoop());
+  appended_row();
 }
 
 // Combine the G lane groups of a wave (flash-decoding merge over lanes LPR, 2*LPR, ... apart); afterwards every lane

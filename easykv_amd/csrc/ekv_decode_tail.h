@@ -96,7 +96,22 @@ using Red4 = RedN<4>;
 
 // Score rows of (layer, head) -> LDS by asynchronous LDS-DMA (1 KiB per wave-instruction); the ragged end by plain
 // loads.  The data is complete after the caller's next __syncthreads() (vmcnt(0) precedes the barrier).
+// The ragged end of the score rows (the last W % 256 columns) by plain loads.  Separate from the DMA part so that a caller can
+// issue the DMA early and keep these loads (whose LDS stores wait for them) out of the way of its own first loads.
 template <int NW = 4>
+__device__ __forceinline__ void ekv_tail_prefetch_ragged(const EkvScoreArgs& sc, size_t head_row, int W, bool roco, float* sS,
+                                                         float* sQ, float* sC) {
+  const int tid = threadIdx.x;
+  for (int j = W / 256 * 256 + tid; j < W; j += 64 * NW) {
+    sS[j] = sc.score_sum[head_row + j];
+    if (roco) {
+      sQ[j] = sc.score_sq[head_row + j];
+      sC[j] = sc.score_cnt[head_row + j];
+    }
+  }
+}
+
+template <int NW = 4, bool RAGGED = true>
 __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, size_t head_row, int W, int w_pad, bool roco,
                                                        float* sS, float* sQ, float* sC) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,13 +123,7 @@ __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, s
     float* dst = sS + (size_t)arr * w_pad + ch * 256;     // wave-uniform base; lane i lands at +16*i bytes
     __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
-  for (int j = full * 256 + tid; j < W; j += 64 * NW) {
-    sS[j] = sc.score_sum[head_row + j];
-    if (roco) {
-      sQ[j] = sc.score_sq[head_row + j];
-      sC[j] = sc.score_cnt[head_row + j];
-    }
-  }
+  if (RAGGED) ekv_tail_prefetch_ragged<NW>(sc, head_row, W, roco, sS, sQ, sC);
 }
 
 // PHYS: s_logit is indexed by PHYSICAL row (the fused kernel streamed the rows in address order); the logit of position
