@@ -136,9 +136,16 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
                                                 const float* part_max = nullptr, int n_part = 0, int part_stride = 0) {
   const int tid = threadIdx.x;
   constexpr int NT = 64 * NW;
-  // PHYS: cell[it] = physical row of position tid + it * NT (loaded once; also feeds the slot-map shift at the end)
-  int cell[PHYS ? ITEMS : 1];
+  // cell[it] = physical row of position tid + it * NT, loaded once up front: PHYS reads the logits through it, and the
+  // slot-map shift at the end writes straight from these registers (no dependent re-read + barrier at the very end)
+  int cell[ITEMS];
   bool have_cells = false;
+  if (!PHYS && sc.n_evict == 1) {
+    const int32_t* map0 = sc.slot_of_pos + head_row;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) cell[it] = map0[min(tid + it * NT, T - 1)];
+    have_cells = true;
+  }
   const bool roco = sc.policy == EKV_POLICY_ROCO;
   const bool scored = roco || sc.policy == EKV_POLICY_H2O_HEAD || sc.policy == EKV_POLICY_TOVA;
 #ifdef EKV_TAIL_PROFILE
@@ -413,7 +420,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
     // read everything that moves, barrier, then write (the row belongs to this workgroup only)
     const int pv = off + victim;
     int32_t* map = sc.slot_of_pos + head_row;
-    if (PHYS && have_cells) {
+    if (have_cells) {
       // every thread still holds the map entries of its positions: nothing to read, no barrier
 #pragma unroll
       for (int it = 0; it < ITEMS; ++it) {
