@@ -216,6 +216,9 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
       }
     }
     red.template sum_n<REP>(sm);
+    float inv_sm[REP];     // p = e * (1 / sum): see ekv_score_select.inc on why not a division per element
+#pragma unroll
+    for (int r = 0; r < REP; ++r) inv_sm[r] = 1.f / sm[r];
     // off + j == a column this thread wrote itself only when off % NT == 0; otherwise wait for the other writers
     if ((off % NT) != 0) __syncthreads();
     if (PHYS) {
@@ -225,7 +228,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
         if (j < W) {
           float pb = 0.f;
 #pragma unroll
-          for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + cell_off[it]] / sm[r];
+          for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + cell_off[it]] * inv_sm[r];
           if (REP > 1) pb = pb / (float)REP;
           if (sc.policy == EKV_POLICY_TOVA) {
             sS[j] = pb;
@@ -240,7 +243,7 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
       for (int j = tid; j < W; j += NT) {
         float pb = 0.f;
 #pragma unroll
-        for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + off + j] / sm[r];
+        for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + off + j] * inv_sm[r];
         if (REP > 1) pb = pb / (float)REP;
         if (sc.policy == EKV_POLICY_TOVA) {
           sS[j] = pb;
