@@ -36,7 +36,9 @@ def _worker(rank, world, port, n_layers, out_q):
         D.ring_handoff(hidden, recv, shard)     # every rank takes part in every exchange (ring)
         D.barrier()
     t = D.max_over_ranks(float(r + 1))
-    out_q.put((r, shard.begin, shard.end, hidden.clone(), recv.clone(), t))
+    # plain lists, not tensors: a tensor crosses a torch.multiprocessing queue as a shared-memory handle, and the parent fails
+    # with EOFError if this process has exited before the handle is opened (seen once under load)
+    out_q.put((r, shard.begin, shard.end, hidden.flatten().tolist(), recv.flatten().tolist(), t))
     D.barrier()
     torch.distributed.destroy_process_group()
 
@@ -69,6 +71,7 @@ def test_two_rank_pipeline_handoff():
     for l in range(n_layers):
         ref = _stage(ref, l)
     (r0, b0, e0, h0, recv0, t0), (r1, b1, e1, h1, recv1, t1) = res
+    h1, recv0 = torch.tensor(h1).view(1, 8), torch.tensor(recv0).view(1, 8)
     assert (b0, e0, b1, e1) == (0, 3, 3, 6)
     assert torch.allclose(h1, ref)            # the last stage holds the full-depth result
     assert torch.allclose(recv0, h1)          # ...and the ring returns it to stage 0 (next token's input)
