@@ -97,6 +97,21 @@ def device_copy_gbs(dev, nbytes=1 << 30, iters=8):
     return 2.0 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def device_read_gbs(dev, nbytes=1 << 30, iters=10):
+    """Read-only counterpart: the fastest stock reduction found on this GPU (row-wise amax over 1 GiB of fp32, 4096 rows);
+    torch.sum / torch.max over the flat tensor reach 3.7-4.0 TB/s, this one ~6.0 TB/s."""
+    x = torch.ones(4096, nbytes // 4 // 4096, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        x.amax(dim=1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        x.amax(dim=1)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return float(x.numel() * 4) * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def event_overhead_us(dev, reps=32):
     """What a HIP-event pair adds around ONE kernel launch: events around a one-element kernel (whose own run time is ~2 us).
     Informational: `roofline.achieved` uses the raw event durations (conservative); the rocprofv3 kernel trace under
@@ -384,6 +399,9 @@ def main():
             copy = device_copy_gbs(dev)
             line["roofline"]["device_copy_gbs"] = copy      # measured read+write copy bandwidth of this GPU
             line["roofline"]["frac_of_device_copy"] = gbs / copy
+            rd = device_read_gbs(dev)
+            line["roofline"]["device_read_gbs"] = rd        # best stock read-only kernel (torch row-wise amax) on this GPU
+            line["roofline"]["frac_of_device_read"] = gbs / rd
             line["roofline"]["event_pair_around_1elem_kernel_us"] = event_overhead_us(dev)
             line["roofline"]["timing"] = ("HIP event pair around every launch" if per_step_events else
                                           "one HIP event pair around the timed region / steps (launches are back to back)")
