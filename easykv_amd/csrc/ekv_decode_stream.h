@@ -84,8 +84,11 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     other.z = __shfl_xor(kv.z, LPR / 2, 64);
     other.w = __shfl_xor(kv.w, LPR / 2, 64);
     const ekv_h8 kh = __builtin_bit_cast(ekv_h8, kv), oh = __builtin_bit_cast(ekv_h8, other);
-    const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)j * D + sub * 8);
-    const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)j * D + sub * 8);
+    // the tables are cat(freqs, freqs) (llama_patch.py:74-98; checked by KVBank.set_rope): both halves of the lane group read
+    // the FIRST half of the row, so a wave touches half as many table lines — the loop moved 4x more table than K bytes
+    // through the texture path (two fp32 tables against one fp16 row)
+    const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)j * D + (sub % (LPR / 2)) * 8);
+    const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)j * D + (sub % (LPR / 2)) * 8);
     const float4 c0 = c4[0], c1 = c4[1], s0 = s4[0], s1 = s4[1];
     const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};

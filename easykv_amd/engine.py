@@ -105,6 +105,11 @@ class KVBank:
         """fp32 tables ``[>= cap, head_dim]`` for the streaming (rope-on-read) variant."""
         self.rope_cos = cos.to(self.device, torch.float32).contiguous()
         self.rope_sin = sin.to(self.device, torch.float32).contiguous()
+        half = self.head_dim // 2
+        # the kernels read only the first half of a table row for both halves of the head (the reference's tables are
+        # cat(freqs, freqs), llama_patch.py:74-98 / HF rotary modules)
+        if not (torch.equal(self.rope_cos[:, :half], self.rope_cos[:, half:]) and torch.equal(self.rope_sin[:, :half], self.rope_sin[:, half:])):
+            raise _lib.EkvError("rope tables must have the cat(freqs, freqs) layout (equal halves along head_dim)")
 
     # -- data movement at the boundary -------------------------------------------------------------
     def load_rows(self, k, v, pos_begin=None, layer_begin=0):

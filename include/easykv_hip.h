@@ -131,7 +131,8 @@ int ekv_state_init(const ekv_bank *bank, int32_t layer_begin, int32_t layer_coun
  *   v_new  fp16 [layer_count][n_kv_heads][q_len][head_dim]
  *   out    fp16 [layer_count][n_q_heads][q_len][head_dim]
  *   evict_ids int32 [layer_count][n_kv_heads][n_evict] or NULL: evicted logical positions, ascending
- *   rope_cos/rope_sin fp32 [>= n_slots][head_dim] or NULL
+ *   rope_cos/rope_sin fp32 [>= n_slots][head_dim] or NULL; layout cat(freqs, freqs) as in the reference (llama_patch.py:74-98):
+ *                    the kernels read the first half of a row for both halves of the head
  * After the call the bank holds n_slots - n_evict live positions (the caller tracks that number). */
 int ekv_step_attend(const ekv_bank *bank, const ekv_step *step, const void *q, const void *k_new, const void *v_new,
                     void *out, int32_t *evict_ids, const float *rope_cos, const float *rope_sin, void *workspace,
