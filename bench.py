@@ -10,13 +10,15 @@ path.  The metric is BASELINE.json's: decode tokens/s (path only) + HBM GB/s of 
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU.  Layer blocks are independent
-units (eviction state is per (layer, head)), so every rank owns a 32-layer block and runs the
-same step with no data-path collective (weak scaling); the pipeline hand-off of the north star
-(one [1, hidden] fp16 activation per stage boundary) is issued as an RCCL ring send/recv per step, posted
-after the step's kernels and waited for at the next step (stages of a pipeline work on different tokens).
-The rank-0 line also carries `roofline` (dominant kernel, HIP events) and `cpu_baseline` (the
-oracle timed on the host cores of the same box, bounded sample).
+N > 1 is launched by torch.distributed.run, one rank per GPU.  Eviction state is per (layer, head), so layers
+shard as contiguous blocks with no data-path collective.  `--scaling strong` (default): the ONE
+Llama2-7B-shaped model is split over the ranks, 32/N layers each — a full pipeline, every stage busy with a different
+sequence's token each step; the stage's real output ([1, Hq*D] fp16, the attention output of its last layer) goes to
+the next rank by an RCCL point-to-point pair per step, and a stage launches step i+1 only after the activation of step i
+has arrived (`--handoff overlap` posts it behind the next launch instead).  `--scaling weak` (also reported as a second
+key at N > 1): every rank owns a whole 32-layer block.  The rank-0 line carries `roofline` (dominant kernel, HIP events),
+`cpu_baseline` (the oracle timed on the host cores of the same box, bounded sample), `strided_prefill` (configs[1] and the
+wider strides of Bench-P) and `boundary_kernels` (gather / scatter / in-place compaction bandwidth).
 """
 from __future__ import annotations
 
@@ -43,42 +45,77 @@ def algorithmic_bytes(H, Hq, D, T, q_len, n_state, e=2):
     return dict(attn=kv + qo // 2 + new, score=state + qo // 2, total=kv + qo + new + state)
 
 
-def cpu_baseline(args, budget, policy, seconds=12.0):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, budget, policy, seconds=10.0):
     """The oracle (reference-shaped CPU path: torch.cat append, fp32 softmax, topk, boolean-mask
-    compaction — easykv/easykv.py:56-68, :287-333) on a bounded sample of the same workload."""
+    compaction — easykv/easykv.py:56-68, :287-333) on a bounded sample of the same workload: WHOLE decode tokens over all
+    `--layers` layers at the full T (no extrapolation from a few layers).  Headline: fp32 state on <= 16 threads, the sweet
+    spot of these small torch ops on the GPU box's EPYC host; `variants` adds the two other forms SURVEY.md §8d names —
+    fp16 storage (K/V kept in fp16, widened for the step and narrowed again, what a CPU run of the reference's fp16
+    configuration pays) and the reference's default thread count (all cores)."""
     from oracle import easykv_oracle as O
     H = Hq = args.heads
-    D, T = args.head_dim, budget + 1
-    # 8-16 threads is the sweet spot of these small torch ops on the GPU box's EPYC host (measured: 8/16 threads
-    # ~28 ms per layer-step, 64 threads ~100 ms, 256 threads seconds); the reference's default (all cores) is slower
-    ncpu = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(ncpu)
+    L, D, T = args.layers, args.head_dim, budget + 1
     g = torch.Generator().manual_seed(1234)
-    L = 2
-    states = []
-    for _ in range(L):
-        st = O.LayerState(k=torch.randn(1, H, budget, D, generator=g).half().float(),
-                          v=torch.randn(1, H, budget, D, generator=g).half().float())
-        st.s, st.q, st.c = O.init_state_decoding((H,), budget)
-        st.s += torch.rand(H, T, generator=g) * 1e-3
-        st.q += st.s ** 2
-        states.append(st)
+    base_k = torch.randn(1, H, budget, D, generator=g).half()
+    base_v = torch.randn(1, H, budget, D, generator=g).half()
+
+    def fresh_states(dtype):
+        states = []
+        for l in range(L):
+            st = O.LayerState(k=torch.roll(base_k, l, dims=2).to(dtype), v=torch.roll(base_v, l, dims=2).to(dtype))
+            st.s, st.q, st.c = O.init_state_decoding((H,), budget)
+            st.s += torch.rand(H, T, generator=g) * 1e-3
+            st.q += st.s ** 2
+            states.append(st)
+        return states
+
     plan = O.StepPlan(policy=policy, phase="decode", evict=True, score_off=0, budget=budget)
-    n_ls, t0 = 0, time.perf_counter()
-    while True:
-        for st in states:
-            q = torch.randn(1, Hq, 1, D, generator=g).half().float()
-            k = torch.randn(1, H, 1, D, generator=g).half().float()
-            v = torch.randn(1, H, 1, D, generator=g).half().float()
-            O.layer_step(st, q, k, v, plan)
-            n_ls += 1
-        el = time.perf_counter() - t0
-        if el > seconds or n_ls >= 4000:
-            break
-    per_token = el / n_ls * args.layers
-    return dict(value=1.0 / per_token, unit="tokens/s", cores=ncpu, kind="port",
-                sample=f"{n_ls} layer-steps (L={L} layers x {n_ls // L} decode steps) at full T={T}, H={H}, D={D}, fp32, "
-                       f"{policy}; per-token = {args.layers} x mean layer-step ({el / n_ls * 1e3:.2f} ms)")
+
+    def run(threads, fp16_storage, secs):
+        torch.set_num_threads(threads)
+        states = fresh_states(torch.float16 if fp16_storage else torch.float32)
+        n_tok, t0 = 0, time.perf_counter()
+        while True:
+            for st in states:
+                q = torch.randn(1, Hq, 1, D, generator=g).half().float()
+                k = torch.randn(1, H, 1, D, generator=g).half().float()
+                v = torch.randn(1, H, 1, D, generator=g).half().float()
+                if fp16_storage:
+                    st.k, st.v = st.k.float(), st.v.float()
+                O.layer_step(st, q, k, v, plan)
+                if fp16_storage:
+                    st.k, st.v = st.k.half(), st.v.half()
+            n_tok += 1
+            el = time.perf_counter() - t0
+            if el > secs or n_tok >= 64:
+                break
+        return n_tok / el, n_tok, el
+
+    ncpu = min(16, os.cpu_count() or 1)
+    v0, n0, e0 = run(ncpu, False, seconds)
+    out = dict(value=v0, unit="tokens/s", cores=ncpu, kind="port", cpu=_cpu_model(), host_threads_available=os.cpu_count(),
+               sample=f"{n0} whole decode tokens x {L} layers ({n0 * L} layer-steps, {e0:.1f} s) at full T={T}, H={H}, D={D}, fp32 state, "
+                      f"{policy}, reference-shaped (torch.cat append, topk, boolean-mask compaction)")
+    variants = []
+    v1, n1, e1 = run(ncpu, True, seconds * 0.6)
+    variants.append(dict(name="fp16_storage", value=v1, unit="tokens/s", cores=ncpu, sample=f"{n1} tokens x {L} layers, {e1:.1f} s"))
+    if (os.cpu_count() or 1) > ncpu:
+        v2, n2, e2 = run(os.cpu_count(), False, seconds * 0.6)
+        variants.append(dict(name="all_cores_fp32", value=v2, unit="tokens/s", cores=os.cpu_count(),
+                             sample=f"{n2} tokens x {L} layers, {e2:.1f} s (the reference's default: torch uses every core)"))
+    out["variants"] = variants
+    torch.set_num_threads(ncpu)
+    return out
 
 
 def device_copy_gbs(dev, nbytes=1 << 30, iters=8):
@@ -129,14 +166,14 @@ def event_overhead_us(dev, reps=32):
     return v[len(v) // 2]
 
 
-def strided_prefill(args, dev, n_chunks=48, warm=8):
-    """Secondary figure (never `value`): BASELINE.json configs[1] — the chunk phase of a strided prefill, S=4096, stride 8,
-    budget 0.5, kv_policy roco (SURVEY.md §8d Bench-P): the cache oscillates idx <-> idx+stride, every chunk step attends
-    the retained slots with 8 queries per head, scores and evicts 8 slots per (layer, head); all layers in one launch pair."""
+def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
+    """Secondary figures (never `value`): the chunk phase of a strided prefill (SURVEY.md §8d Bench-P).  Default = BASELINE.json
+    configs[1]: S=4096, stride 8, budget 0.5, kv_policy roco; also run at stride 64 / 96 and at the configs[3] shape
+    (S=9994, stride 96).  The cache oscillates idx <-> idx+stride, every chunk step attends the retained slots with `stride`
+    queries per head, scores and evicts `stride` slots per (layer, head); all layers in one launch (pair)."""
     from easykv_amd import KVBank, StepPlan, geometry
     L, Hq, D = args.layers, args.heads, args.head_dim
     H = args.kv_heads or Hq
-    S, stride = 4096, 8
     bp, idx, r_idx = geometry("encoding", S, 0.5, stride)
     g = torch.Generator(device=dev).manual_seed(4321)
     rnd = lambda h, n: torch.randn(L, h, n, D, generator=g, device=dev).half()
@@ -191,52 +228,79 @@ def strided_prefill(args, dev, n_chunks=48, warm=8):
             "slot_map": "identity" if args.identity_layout else "scattered"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--layers", type=int, default=32)
-    ap.add_argument("--heads", type=int, default=32)
-    ap.add_argument("--kv-heads", type=int, default=0)
-    ap.add_argument("--head-dim", type=int, default=128)
-    ap.add_argument("--budget", type=int, default=2048)
-    ap.add_argument("--policy", default="roco")
-    ap.add_argument("--layers-per-launch", type=int, default=0, help="0 = all layers of the rank in one launch")
-    ap.add_argument("--n-split", type=int, default=0, help="key-range splits per head (0 = library default)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--step-events", action="store_true", help="fused path: bracket every launch with its own HIP event pair instead "
-                    "of one pair around the timed region (adds ~6 us of marker latency per step)")
-    ap.add_argument("--no-prefill", action="store_true", help="skip the secondary strided-prefill (configs[1]) figure")
-    ap.add_argument("--no-handoff", action="store_true")
-    ap.add_argument("--split-kernels", action="store_true", help="force the two-kernel path (attention + score/select)")
-    ap.add_argument("--overlap-scorer", action="store_true", help="split path: run the scorer on side streams, off the critical path")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
-    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0 (multi-rank smoke test on a 1-GPU box)")
-    ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed pre-warm of clocks and score state before the warmup steps (seconds)")
-    ap.add_argument("--identity-layout", action="store_true", help="start from a fresh bank's identity slot map (position order == "
-                    "address order) instead of the scattered steady-state layout")
-    ap.add_argument("--graph", action="store_true", help="capture one step (all launches) in a hipGraph and replay it")
-    args = ap.parse_args()
+def boundary_kernels(args, dev, iters=6):
+    """Bandwidth of the kernels at the drop-in boundary (not on the per-token path): the ordered gather that hands the legacy
+    ``past_key_values`` tuple back (ekv_gather_ordered), the import of ordered rows (ekv_scatter_rows) and the reference-shaped
+    physical compaction (ekv_compact_inplace, easykv/easykv.py:56-82), at the Llama2-7B shape.  Charges:
+    gather / scatter move every row once in and once out, 2 x (2 H T D e) per layer; the in-place compaction moves the rows
+    behind each head's first victim, 4 * sum_h (T - 1 - v_h) * D * e per layer (K and V, read + write)."""
+    from easykv_amd import KVBank
+    L, Hq, D = args.layers, args.heads, args.head_dim
+    H = args.kv_heads or Hq
+    T = args.budget + 1
+    g = torch.Generator(device=dev).manual_seed(99)
+    bank = KVBank(L, Hq, H, D, cap=T + 63, device=dev)
+    k = torch.randn(L, H, T, D, generator=g, device=dev).half()
+    v = torch.randn(L, H, T, D, generator=g, device=dev).half()
+    bank.load_rows(k, v)
+    perm = torch.argsort(torch.rand(L, H, T, generator=g, device=dev), dim=-1).int()
 
-    from easykv_amd import dist as DS
-    if args.same_device:
-        os.environ["LOCAL_RANK"] = "0"
-    rank, local_rank, world = DS.init(args.backend)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
-    shard = DS.LayerShard(rank, world, args.layers * world)   # weak scaling: every rank owns a block of `layers` layers
+    def timed(fn, setup=None):
+        ts = []
+        for i in range(iters + 2):
+            if setup is not None:
+                setup()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            if i >= 2:
+                ts.append(e0.elapsed_time(e1) * 1e-3)
+        return sum(ts) / len(ts)
 
+    out = {}
+    io_bytes = 2 * (2 * L * H * T * D * 2)
+
+    def scat():
+        bank.n_slots = [0] * L
+        bank.load_rows(k, v, pos_begin=0)
+    t = timed(scat)
+    out["ekv_scatter_rows"] = {"us": t * 1e6, "bytes": io_bytes, "gbs": io_bytes / t / 1e9, "layout": "identity"}
+    t = timed(lambda: bank.ordered_kv())
+    out["ekv_gather_ordered"] = {"us": t * 1e6, "bytes": io_bytes, "gbs": io_bytes / t / 1e9, "layout": "identity"}
+    bank.slot_of_pos[:, :, :T] = perm
+    t = timed(lambda: bank.ordered_kv())
+    out["ekv_gather_ordered_scattered"] = {"us": t * 1e6, "bytes": io_bytes, "gbs": io_bytes / t / 1e9,
+                                           "layout": "scattered slot map (random permutation of 256-byte rows)"}
+    bank.reset()
+    bank.load_rows(k, v)
+    victims = torch.randint(0, T - 1, (L, H, 1), generator=g, device=dev, dtype=torch.int32)    # one victim per head (a decode step)
+    moved = 4 * int((T - 1 - victims.long()).sum()) * D * 2
+
+    def restore():
+        bank.n_slots = [T] * L
+    t = timed(lambda: bank.compact_inplace(victims), restore)
+    out["ekv_compact_inplace"] = {"us": t * 1e6, "bytes": moved, "gbs": moved / t / 1e9, "victims_per_head": 1,
+                                  "charge": "4 * sum_h (T - 1 - v_h) * D * e"}
+    for name in out:
+        out[name]["frac_of_hbm_peak"] = out[name]["gbs"] / HBM_PEAK_GBS
+    out["shape"] = f"L={L} H={H} T={T} D={D} fp16"
+    return out
+
+
+def decode_run(args, dev, rank, world, scaling, DS, want_seq):
+    """One timed Bench-D run.  scaling 'strong': the `--layers`-layer model is split over the ranks (this rank owns its
+    LayerShard block); 'weak': every rank owns `--layers` layers."""
     from easykv_amd import KVBank, StepPlan
-
-    L, Hq, D, budget = args.layers, args.heads, args.head_dim, args.budget
+    Hq, D, budget = args.heads, args.head_dim, args.budget
     H = args.kv_heads or Hq
     T = budget + 1
+    shard = DS.LayerShard(rank, world, args.layers if scaling == "strong" else args.layers * world)
+    L = shard.count                     # layers of this rank
     n_total = args.steps + args.warmup
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    bank = KVBank(L, Hq, H, D, cap=T + 63)
+    bank = KVBank(L, Hq, H, D, cap=T + 63, device=dev)
     # cache pre-filled to `budget` retained slots (synthetic warm state, SURVEY.md §8d Bench-D)
     for l0 in range(0, L, 8):
         lc = min(8, L - l0)
@@ -252,22 +316,32 @@ def main():
     qs = torch.randn(n_total, L, Hq, 1, D, generator=gen, device=dev).half()
     ks = torch.randn(n_total, L, H, 1, D, generator=gen, device=dev).half()
     vs = torch.randn(n_total, L, H, 1, D, generator=gen, device=dev).half()
-    out = torch.empty(L, Hq, 1, D, dtype=torch.float16, device=dev)
+    # two output buffers in turn: the stage output of step i (the attention output of the rank's LAST layer) is sent straight
+    # from outs[i % 2] while step i + 1 writes the other one
+    outs = [torch.empty(L, Hq, 1, D, dtype=torch.float16, device=dev) for _ in range(2)]
+    hidden_in = [torch.zeros(1, Hq * D, dtype=torch.float16, device=dev) for _ in range(2)]
     ids = torch.empty(L, H, 1, dtype=torch.int32, device=dev)
     plan = StepPlan(policy=args.policy, phase="decode", evict=True, score_off=0, budget=budget, n_split=args.n_split)
     if args.policy == "recency":
         plan.range_start = 0
-    lpl = args.layers_per_launch or L
-    hidden = torch.zeros(1, Hq * D, dtype=torch.float16, device=dev)
-    hidden_in = torch.zeros_like(hidden)
+    lpl = min(args.layers_per_launch or L, L)
+    handoff_on = world > 1 and not args.no_handoff and not args.graph
+    sync_handoff = handoff_on and args.handoff == "sync"
 
     pending = []      # requests of the hand-off still in flight (world > 1)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    n_split, fused = bank.step_plan(plan, 1, 0, min(lpl, L))
+    n_split, fused = bank.step_plan(plan, 1, 0, lpl)
     if args.split_kernels:
         fused = False
+    st = {"i": 0}
 
     def step(i, timed_idx=None, handoff=True):
+        out = outs[st["i"] & 1]
+        if handoff and sync_handoff:
+            # a pipeline stage consumes the previous stage's activation: the launch is ordered behind its arrival
+            for req in pending:
+                req.wait()
+            pending.clear()
         for l0 in range(0, L, lpl):
             lc = min(lpl, L - l0)
             a = (plan, qs[i, l0:l0 + lc], ks[i, l0:l0 + lc], vs[i, l0:l0 + lc])
@@ -292,9 +366,13 @@ def main():
                 bank.attend(*a, overlap_scorer=args.overlap_scorer, **kw)
         if args.overlap_scorer and args.graph:
             bank.join()        # a captured step must end with every forked stream joined
-        if handoff and world > 1 and not args.no_handoff and not args.graph:   # pipeline hand-off of the stage output (north star):
-            # posted after this step's kernels, waited for at the next step, so the 8 KB transfer overlaps the next launch
-            pending[:] = DS.ring_handoff_async(hidden, hidden_in, shard, pending)
+        if handoff and handoff_on:   # pipeline hand-off of the stage output (north star)
+            send = out[L - 1].view(1, Hq * D)
+            if sync_handoff:
+                pending[:] = DS.ring_handoff_async(send, hidden_in[st["i"] & 1], shard, None)
+            else:   # posted after this step's kernels, waited for after the next launch: the transfer overlaps it
+                pending[:] = DS.ring_handoff_async(send, hidden_in[st["i"] & 1], shard, pending)
+        st["i"] += 1
 
     # Clock / state pre-warm (untimed, before the W warmup steps): the same step for --prewarm-s seconds of wall time.  A cold
     # GPU needs tens of ms of load before its clocks settle, and the roco state needs ~1000 steps to reach the steady state the
@@ -316,6 +394,7 @@ def main():
         sq, sk, sv = qs[0].clone(), ks[0].clone(), vs[0].clone()
         qs_src, ks_src, vs_src = qs, ks, vs
         qs, ks, vs = sq.unsqueeze(0), sk.unsqueeze(0), sv.unsqueeze(0)     # step() now reads the static inputs (index 0)
+        st["i"] = 0
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -354,55 +433,142 @@ def main():
 
     # secondary figure (not `value`): the same step issued one layer per launch, as a real sequential model does
     seq = None
-    if rank == 0 and lpl == L and not args.graph and L > 1:
+    if want_seq and lpl == L and not args.graph and L > 1:
         n_seq = max(4, min(16, args.steps))
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for i in range(n_seq):
-            for l0 in range(L):
-                bank.attend(plan, qs[i, l0:l0 + 1], ks[i, l0:l0 + 1], vs[i, l0:l0 + 1], layer_begin=l0, out=out[l0:l0 + 1], evict_ids=ids[l0:l0 + 1])
-        torch.cuda.synchronize()
-        seq = n_seq / (time.perf_counter() - ts)
+        out = outs[0]
+        for rep_ in range(2):     # first pass warms the per-layer plan cache / code path
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for i in range(n_seq):
+                for l0 in range(L):
+                    bank.attend(plan, qs[i, l0:l0 + 1], ks[i, l0:l0 + 1], vs[i, l0:l0 + 1], layer_begin=l0, out=out[l0:l0 + 1], evict_ids=ids[l0:l0 + 1])
+            torch.cuda.synchronize()
+            seq = n_seq / (time.perf_counter() - ts)
+    t_region = region[0].elapsed_time(region[1]) / args.steps * 1e-3
+    return dict(elapsed=elapsed, t_region=t_region, ev=ev, per_step_events=per_step_events, n_split=n_split, fused=fused, lpl=lpl,
+                L=L, shard=shard, n_pre=n_pre, seq=seq, handoff=handoff_on, sync_handoff=sync_handoff, T=T, H=H)
+
+
+def latest_pmc_summary(L, Hq, H, D, budget, policy, lpl):
+    """HBM traffic of the fused kernel from the newest rocprofv3 PMC summary committed under profiles/ (FETCH_SIZE / WRITE_SIZE in
+    separate passes, 2 x FETCH + WRITE: the guide's gfx950 correction).  Counters cannot be read from inside this process;
+    the summary is re-collected every round with the same command (tools/summarize_prof.py) and named per round."""
+    import glob
+    import re
+    if (L, Hq, H, D, budget, policy, lpl) != (32, 32, 32, 128, 2048, "roco", 32):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_decode_summary.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    for f in reversed(files):
+        try:
+            pm = json.load(open(f)).get("pmc", {})
+            k = [v for n, v in pm.items() if "ekv_decode_fused_kernel<128, 1, false" in n]
+            if k and "hbm_bytes_per_launch" in k[0]:
+                return k[0]["hbm_bytes_per_launch"], (f"profiles/{os.path.basename(f)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                                      "passes, 2 x FETCH + WRITE (gfx950 correction), same bench command")
+        except Exception:
+            continue
+    return None, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=0)
+    ap.add_argument("--head-dim", type=int, default=128)
+    ap.add_argument("--budget", type=int, default=2048)
+    ap.add_argument("--policy", default="roco")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: 'strong' splits the ONE --layers-layer model over the ranks (--layers/N each, pipeline hand-off of the "
+                         "real stage output); 'weak' gives every rank a whole --layers-layer block.  At N > 1 the other one is reported as a second key")
+    ap.add_argument("--handoff", choices=("sync", "overlap"), default="sync",
+                    help="sync: a stage launches step i+1 after the activation of step i has arrived (full pipeline, N sequences in "
+                         "flight); overlap: the transfer is waited for after the next launch (2N sequences in flight)")
+    ap.add_argument("--layers-per-launch", type=int, default=0, help="0 = all layers of the rank in one launch")
+    ap.add_argument("--n-split", type=int, default=0, help="key-range splits per head (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-events", action="store_true", help="fused path: bracket every launch with its own HIP event pair instead "
+                    "of one pair around the timed region (adds ~6 us of marker latency per step)")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the secondary strided-prefill (configs[1]) figures")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-kernel bandwidth figures")
+    ap.add_argument("--no-handoff", action="store_true")
+    ap.add_argument("--no-second-scaling", action="store_true", help="N > 1: skip the run in the other scaling mode")
+    ap.add_argument("--split-kernels", action="store_true", help="force the two-kernel path (attention + score/select)")
+    ap.add_argument("--overlap-scorer", action="store_true", help="split path: run the scorer on side streams, off the critical path")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
+    ap.add_argument("--same-device", action="store_true", help="debug: every rank uses cuda:0 (multi-rank smoke test on a 1-GPU box)")
+    ap.add_argument("--prewarm-s", type=float, default=1.0, help="untimed pre-warm of clocks and score state before the warmup steps (seconds)")
+    ap.add_argument("--identity-layout", action="store_true", help="start from a fresh bank's identity slot map (position order == "
+                    "address order) instead of the scattered steady-state layout")
+    ap.add_argument("--graph", action="store_true", help="capture one step (all launches) in a hipGraph and replay it")
+    args = ap.parse_args()
+
+    from easykv_amd import dist as DS
+    if args.same_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local_rank, world = DS.init(args.backend)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    if world > 1 and args.scaling == "strong" and args.layers < world:
+        raise SystemExit("--scaling strong needs at least one layer per rank")
+
+    Hq, D, budget = args.heads, args.head_dim, args.budget
+    r = decode_run(args, dev, rank, world, args.scaling, DS, want_seq=(rank == 0 and world == 1))
+    second = None
+    if world > 1 and not args.no_second_scaling and not args.graph:
+        other = "weak" if args.scaling == "strong" else "strong"
+        r2 = decode_run(args, dev, rank, world, other, DS, want_seq=False)
+        tokens2 = args.steps * (world if other == "weak" else 1)
+        second = {"scaling": other, "value": tokens2 / r2["elapsed"], "unit": "tokens/s", "ms_per_step": r2["elapsed"] / args.steps * 1e3,
+                  "layers_per_rank": r2["L"], "fused": r2["fused"], "n_split": r2["n_split"],
+                  "note": "weak: every rank owns a whole 32-layer block (aggregate layer-parallel throughput)" if other == "weak" else
+                          "strong: the 32-layer model split over the ranks"}
     if rank == 0:
+        L, H, T, lpl, fused, ev = r["L"], r["H"], r["T"], r["lpl"], r["fused"], r["ev"]
         n_state = {"roco": 3, "h2o_head": 1, "tova": 1}.get(args.policy, 0)
         b = algorithmic_bytes(H, Hq, D, T, 1, n_state)
         lc0 = min(lpl, L)
-        t_region = region[0].elapsed_time(region[1]) / args.steps * 1e-3
+        t_region, per_step_events = r["t_region"], r["per_step_events"]
         t_attn = t_region if not per_step_events else (1.0 if args.overlap_scorer else sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3)
-        cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={L} Hq={Hq} H={H} D={D} budget={budget} "
+        tokens = args.steps * (world if args.scaling == "weak" else 1)
+        cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={args.layers} Hq={Hq} H={H} D={D} budget={budget} "
                            f"T={T} kv_policy={args.policy} (Llama2-7B shape, budget=50% of S=4096)",
-               "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [shard.begin, shard.end], "n_split": n_split, "fused": fused, "slot_map": "identity" if args.identity_layout else "scattered (random permutation: long-run steady state)", "prewarm_steps": n_pre, "hipgraph": bool(args.graph), "overlap_scorer": bool(args.overlap_scorer),
-               "handoff": (world > 1 and not args.no_handoff and not args.graph)}
+               "parallelism": (f"pp{world}: {args.layers} layers split into contiguous blocks, {L} per rank, point-to-point hand-off of the stage output"
+                               if args.scaling == "strong" else f"{world} x {L}-layer blocks, layer-parallel") if world > 1 else "1 GPU",
+               "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [r["shard"].begin, r["shard"].end], "n_split": r["n_split"],
+               "fused": fused, "slot_map": "identity" if args.identity_layout else "scattered (random permutation: long-run steady state)",
+               "prewarm_steps": r["n_pre"], "hipgraph": bool(args.graph), "overlap_scorer": bool(args.overlap_scorer),
+               "handoff": ("sync: launch ordered behind the previous stage's activation" if r["sync_handoff"] else "overlapped with the next launch") if r["handoff"] else False}
         line = {
-            "metric": "decode_tokens_per_sec", "value": world * args.steps / elapsed, "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 storage / f32 accumulate",
+            "metric": "decode_tokens_per_sec", "value": tokens / r["elapsed"], "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["elapsed"] / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16 storage / f32 accumulate",
             "data": "synthetic", "config": cfg}
-        if seq is not None:
-            line["per_layer_launches"] = {"value": seq, "unit": "tokens/s", "note": "same step, one layer per launch (split path: "
-                                          "attention kernel + scorer kernel per layer), latency-bound; not the headline value"}
-        traffic, traffic_src = None, None
-        summ = os.path.join(ROOT, "profiles", "r01_decode_summary.json")
-        if fused and os.path.exists(summ) and (L, Hq, H, D, budget, args.policy, lpl) == (32, 32, 32, 128, 2048, "roco", 32):
-            try:
-                pm = json.load(open(summ)).get("pmc", {})
-                k = [v for n, v in pm.items() if "ekv_decode_fused_kernel<128, 1, false" in n]
-                if k and "hbm_bytes_per_launch" in k[0]:
-                    traffic, traffic_src = k[0]["hbm_bytes_per_launch"], "profiles/r01_decode_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE (gfx950 correction), same command"
-            except Exception:
-                pass
+        if second is not None:
+            line["second_scaling"] = second
+        if r["seq"] is not None:
+            line["per_layer_launches"] = {"value": r["seq"], "unit": "tokens/s", "note": "same step, one layer per launch, as a sequential "
+                                          "model issues it; latency-bound; not the headline value"}
         if fused:
+            traffic, traffic_src = latest_pmc_summary(args.layers, Hq, H, D, budget, args.policy, lpl) if world == 1 else (None, None)
             gbs = b["total"] * lc0 / t_attn / 1e9
             line["roofline"] = {"bound": "hbm", "kernel": "ekv_decode_fused_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                 "bytes_per_launch": b["total"] * lc0, "avg_launch_us": t_attn * 1e6}
-            copy = device_copy_gbs(dev)
-            line["roofline"]["device_copy_gbs"] = copy      # measured read+write copy bandwidth of this GPU
-            line["roofline"]["frac_of_device_copy"] = gbs / copy
-            rd = device_read_gbs(dev)
-            line["roofline"]["device_read_gbs"] = rd        # best stock read-only kernel (torch row-wise amax) on this GPU
-            line["roofline"]["frac_of_device_read"] = gbs / rd
-            line["roofline"]["event_pair_around_1elem_kernel_us"] = event_overhead_us(dev)
+            if world == 1:
+                copy = device_copy_gbs(dev)
+                line["roofline"]["device_copy_gbs"] = copy      # measured read+write copy bandwidth of this GPU
+                line["roofline"]["frac_of_device_copy"] = gbs / copy
+                rd = device_read_gbs(dev)
+                line["roofline"]["device_read_gbs"] = rd        # best stock read-only kernel (torch row-wise amax) on this GPU
+                line["roofline"]["frac_of_device_read"] = gbs / rd
+                line["roofline"]["event_pair_around_1elem_kernel_us"] = event_overhead_us(dev)
             line["roofline"]["timing"] = ("HIP event pair around every launch" if per_step_events else
                                           "one HIP event pair around the timed region / steps (launches are back to back)")
         elif args.overlap_scorer:
@@ -414,12 +580,17 @@ def main():
             line["roofline"] = {"bound": "hbm", "kernel": "ekv_attn_decode_kernel", "achieved": attn_gbs, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": attn_gbs / HBM_PEAK_GBS, "traffic": None,
                                 "bytes_per_launch": b["attn"] * lc0, "avg_launch_us": t_attn * 1e6}
-            line["roofline_step"] = {"kernels": "ekv_attn_decode_kernel + ekv_score_select_kernel", "achieved": step_gbs,
+            line["roofline_step"] = {"kernels": "ekv_attn_decode_kernel + ekv_decode_score_kernel", "achieved": step_gbs,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
                                      "bytes_per_step_launches": b["total"] * lc0, "avg_us": (t_attn + t_score) * 1e6,
                                      "score_select_us": t_score * 1e6}
         if world == 1 and not args.no_prefill and not args.graph:
             line["strided_prefill"] = strided_prefill(args, dev)
+            line["strided_prefill_more"] = [strided_prefill(args, dev, S=4096, stride=64, n_chunks=24),
+                                            strided_prefill(args, dev, S=4096, stride=96, n_chunks=16),
+                                            strided_prefill(args, dev, S=9994, stride=96, n_chunks=16)]
+        if world == 1 and not args.no_boundary and not args.graph:
+            line["boundary_kernels"] = boundary_kernels(args, dev)
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args, budget, args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco")
         print(json.dumps(line))

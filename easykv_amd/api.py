@@ -23,6 +23,8 @@ Model contract (what ``self`` must provide; the reference's is SURVEY.md §8b):
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import functools
 import math
 import statistics
@@ -64,45 +66,87 @@ def geometry(mode: str, length: int, budget, stride: int):
 # ------------------------------------------------------------------------------------------------
 # the cache object handed to the model
 # ------------------------------------------------------------------------------------------------
+# The cache of the model forward in flight, for attention seams that are not handed ``past_key_values`` (easykv_amd.hf's
+# AttentionInterface function).  A context variable, set around every forward by :func:`generate` and reset afterwards: two
+# models, nested or interleaved generates and threads cannot see each other's cache, and a forward outside easykv_generate()
+# finds nothing (the seam then raises instead of appending into a stale bank).
+_ACTIVE: contextvars.ContextVar = contextvars.ContextVar("easykv_amd_active_cache", default=None)
+
+
+def active_cache():
+    """The :class:`BudgetedKVCache` of the forward in flight in this context, or None."""
+    return _ACTIVE.get()
+
+
 class BudgetedKVCache:
     """Device-resident budgeted cache of one sequence.  The driver sets :attr:`plan` before each model
     forward; every attention layer then calls :meth:`attend`.  It also duck-types the two ``Cache`` methods HF
     transformers >= 5 calls on ``past_key_values`` (``update`` hands the new rows straight back: the bank appends them
-    inside :meth:`attend`)."""
+    inside :meth:`attend`).
 
-    current = None     # the cache of the forward in flight (set by begin_forward; read by easykv_amd.hf)
+    ``layer_begin`` / ``layer_count``: the contiguous block of the model's layers THIS process owns (layer sharding,
+    SURVEY.md §8e: the reference spreads layers over GPUs with ``device_map='auto'``, test_passkey.py:25-35; here one process
+    per GPU owns a block, easykv_amd/dist.py).  The bank holds only those layers; :meth:`attend` takes GLOBAL layer indices."""
 
     def __init__(self, n_layers, n_q_heads, n_kv_heads, head_dim, cap, device, streaming=False, rope=None,
-                 record=False):
-        self.bank = KVBank(n_layers, n_q_heads, n_kv_heads, head_dim, cap, device=device)
+                 record=False, layer_begin=0, layer_count=None, rope_base=10000.0):
+        self.layer_begin = layer_begin
+        self.layer_count = n_layers - layer_begin if layer_count is None else layer_count
+        if not (0 <= self.layer_begin and self.layer_count >= 1 and self.layer_begin + self.layer_count <= n_layers):
+            raise ValueError(f"layer block [{layer_begin}, {layer_begin}+{layer_count}) outside the model's {n_layers} layers")
+        self.n_model_layers = n_layers
+        self.bank = KVBank(self.layer_count, n_q_heads, n_kv_heads, head_dim, cap, device=device)
         self.plan = StepPlan(policy="full", phase="prefill", accumulate=False)
         self.streaming = streaming
         self.positions = None    # true position ids of the forward in flight (set by the driver)
         self.unrotate = None     # HF seam + streaming: (cos, sin) fp32 [>= max position, D] to take the model's RoPE off q/k
         if streaming:
-            cos, sin = rope if rope is not None else rope_tables(cap, head_dim)
+            cos, sin = rope[:2] if rope is not None else rope_tables(cap, head_dim, rope_base)
             self.bank.set_rope(cos, sin)
         self.record = record
-        self.evictions = []      # record=True: per forward with eviction: list over layers of int32 [H,k] (device)
+        self.evictions = []      # record=True: per forward with eviction: list over OWNED layers of int32 [H,k] (device)
         self._cur = None
         self.score_prefix = False
+        self.n_attend = 0        # attend() calls of the forward in flight (checked by the driver after every forward)
 
-    def get_seq_length(self, layer_idx: int = 0) -> int:
-        return self.bank.n_slots[layer_idx]
+    def owns(self, layer_idx: int) -> bool:
+        return self.layer_begin <= layer_idx < self.layer_begin + self.layer_count
+
+    def get_seq_length(self, layer_idx: Optional[int] = None) -> int:
+        """Live slots (every owned layer holds the same number, as in the reference)."""
+        return self.bank.n_slots[0 if layer_idx is None or not self.owns(layer_idx) else layer_idx - self.layer_begin]
 
     def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
         return key_states, value_states
 
     def begin_forward(self, plan: StepPlan, positions=None):
-        BudgetedKVCache.current = self
         self.plan = plan
         self.positions = positions
+        self.n_attend = 0
         self._cur = [] if (self.record and plan.evict) else None
         if self._cur is not None:
             self.evictions.append(self._cur)
 
+    @contextlib.contextmanager
+    def active(self, plan: StepPlan, positions=None):
+        """Scope of ONE model forward driven by hand (generate() does this around every forward it issues): sets the plan
+        and makes this cache the one attention seams without a ``past_key_values`` argument (easykv_amd.hf) find."""
+        self.begin_forward(plan, positions)
+        tok = _ACTIVE.set(self)
+        try:
+            yield self
+        finally:
+            _ACTIVE.reset(tok)
+
     def attend(self, layer_idx: int, q, k, v):
-        """One layer of one forward: append + attention + score + select + compaction, all on device."""
+        """One layer of one forward: append + attention + score + select + compaction, all on device.
+        ``layer_idx`` is the layer's index in the MODEL; it must lie in this cache's block."""
+        if not self.owns(layer_idx):
+            raise ValueError(f"layer {layer_idx} is not in this rank's block [{self.layer_begin}, {self.layer_begin + self.layer_count})")
+        if q.shape[0] != 1 or k.shape[0] != 1 or v.shape[0] != 1:
+            raise ValueError("the budgeted-KV path is batch-size 1 (as the reference: easykv/easykv.py asserts nothing but indexes [0])")
+        layer_idx -= self.layer_begin
+        self.n_attend += 1
         plan = self.plan
         n = q.shape[2]
         q = q.to(torch.float16).contiguous()
@@ -174,10 +218,21 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
     use_graph = cfg.get("hipgraph", False)            # extension key: capture the steady-state decode step in a hipGraph
     n_layers, hq, h, d = _dims(self)
     dev = torch.device(self.device)
+    if input_ids.dim() != 2 or input_ids.shape[0] != 1:
+        raise ValueError(f"input_ids must be [1, S] (batch size 1, as the reference); got {tuple(input_ids.shape)}")
     length = input_ids.shape[-1]
     input_ids = input_ids.to(dev)
     scored = policy in SCORED
     evicting = policy in KNOWN_POLICIES and policy != "full"   # unknown strings evict nothing
+
+    # Layer sharding: a model that carries ``layer_shard`` (easykv_amd.dist.LayerShard) runs only its own
+    # block of layers in this process; every rank drives the same loop (the plans depend on lengths only), the bank of a
+    # rank holds its layers only, the model's forward moves the stage output to the next rank, and the sampled token comes
+    # from the last stage.
+    shard = getattr(self, "layer_shard", None)
+    if shard is not None and shard.world == 1:
+        shard = None
+    l_begin, l_count = (shard.begin, shard.count) if shard is not None else (0, n_layers)
 
     if kv_mode == "auto":                                      # easykv/easykv.py:220-227
         assert type(budget) == int
@@ -190,25 +245,91 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
     # streaming variant caches un-rotated keys and rotates by slot index on every read (llama_patch.py:310-327).  The
     # model's own rotary module supplies both the tables for the read-time rotation and the ones to take its rotation off.
     hf_stream = streaming and getattr(self.config, "_attn_implementation", None) == "easykv_amd"
+    if streaming and not hf_stream:
+        # native contract: the rotation at read time uses theta = config.rope_theta (Llama-3: 5e5, Mistral: 1e6); scaled
+        # RoPE variants need the caller's own tables (generation_config['rope_tables'] = (cos, sin) fp32 [>= cap, D])
+        rp = getattr(self.config, "rope_parameters", None) or {}
+        scaling = getattr(self.config, "rope_scaling", None) or (rp if rp.get("rope_type", "default") != "default" else None)
+        if scaling and cfg.get("rope_tables") is None:
+            raise ValueError("streaming=True on a model with scaled RoPE needs generation_config['rope_tables'] = (cos, sin)")
+    rope_base = float(getattr(self.config, "rope_theta", None) or (getattr(self.config, "rope_parameters", None) or {}).get("rope_theta", 10000.0))
 
     def new_cache(cap):
-        hf_rope = None
+        hf_rope = cfg.get("rope_tables")
         if hf_stream:     # tables cover every slot index (< cap) and every true position (< length + max_new_tokens)
             from . import hf
             hf_rope = hf.rope_tables_from_model(self, max(cap + 8, length + max_new_tokens + 1) + 64, d, dev)
-        cache = BudgetedKVCache(n_layers, hq, h, d, cap + 8, dev, streaming=streaming, record=record, rope=hf_rope)
-        cache.unrotate = hf_rope
+        cache = BudgetedKVCache(n_layers, hq, h, d, cap + 8, dev, streaming=streaming, record=record, rope=hf_rope,
+                                layer_begin=l_begin, layer_count=l_count, rope_base=rope_base)
+        cache.unrotate = hf_rope if hf_stream else None
         return cache
 
     def forward(cache, ids, positions, plan):
         plan.streaming = streaming
         pos = torch.as_tensor(positions, dtype=torch.long, device=dev)
-        cache.begin_forward(plan, pos)
-        return self(input_ids=ids, past_key_values=cache, position_ids=pos.view(1, -1), use_cache=True)
+        with cache.active(plan, pos):
+            out = self(input_ids=ids, past_key_values=cache, position_ids=pos.view(1, -1), use_cache=True)
+        # every owned layer must have gone through attend() exactly once: a model whose attention was not routed here
+        # (an un-patched HF model) would otherwise silently run stock attention over the new rows only
+        if cache.n_attend != cache.layer_count:
+            raise RuntimeError(f"model forward made {cache.n_attend} attend() calls for {cache.layer_count} owned layers: route "
+                               "every attention layer through past_key_values.attend (easykv_amd.hf.patch_model for HF models)")
+        return out
+
+    last_rank = shard.world - 1 if shard is not None else 0
 
     def sample(logits_last):
-        prob, raw = logits_adapter(logits_last.float(), temperature, top_p)
-        return torch.multinomial(prob, num_samples=1)
+        """Next token [1, 1] on the device.  Sharded: only the last stage holds the logits; its draw is broadcast."""
+        if shard is None:
+            prob, raw = logits_adapter(logits_last.float(), temperature, top_p)
+            return torch.multinomial(prob, num_samples=1)
+        from . import dist as DS
+        if shard.rank == last_rank:
+            prob, raw = logits_adapter(logits_last.float(), temperature, top_p)
+            tok = torch.multinomial(prob, num_samples=1)
+        else:
+            tok = torch.zeros(1, 1, dtype=torch.long, device=dev)
+        return DS.broadcast(tok, last_rank)
+
+    eos_poll = max(1, int(cfg.get("eos_poll", 16)))   # extension key: host looks at the sampled tokens every N tokens
+
+    class TokenLog:
+        """Sampled tokens stay on the device.  The reference pulls every token to the host to test it for EOS
+        (`.cpu()` / `.item()`, ~5 syncs per token, easykv/easykv.py:257-283); here the host polls the device-side log once per
+        ``eos_poll`` tokens: ONE host sync per ``eos_poll`` tokens.  ``eos_poll=1`` is the reference's exact control flow; with
+        N > 1 up to N-1 forwards run past an EOS before it is seen — wasted work only: the returned text and the printed
+        budget line are those of the reference (cut at the first EOS; counts derived from the EOS index, not from the cache)."""
+
+        def __init__(self):
+            self.buf = torch.empty(max(1, max_new_tokens), dtype=torch.long, device=dev)
+            self.eos = torch.as_tensor([int(e) for e in eos_token_ids], dtype=torch.long, device=dev)
+            self.n = self.checked = self.syncs = 0
+            self.stopped_by_eos = False
+
+        def push(self, tok):
+            self.buf[self.n:self.n + 1].copy_(tok.view(1))
+            self.n += 1
+
+        def poll(self):
+            """True when the loop must stop: an EOS was found among the tokens not looked at yet (``n`` is cut back to it)."""
+            if self.n - self.checked < eos_poll and self.n < max_new_tokens:
+                return False
+            hit = torch.isin(self.buf[self.checked:self.n], self.eos).cpu()     # the one host sync of this poll
+            self.syncs += 1
+            first = self.checked
+            self.checked = self.n
+            if bool(hit.any()):
+                self.n = first + int(torch.nonzero(hit)[0, 0]) + 1
+                self.stopped_by_eos = True
+                return True
+            return False
+
+        def ids(self):
+            return self.buf[:self.n].cpu().tolist()
+
+        @property
+        def fed(self):   # tokens the reference would have fed back into the model (:257-264: the EOS token itself is not)
+            return self.n - 1 if self.stopped_by_eos else self.n
 
     class GraphedStep:
         """One decode forward of the WHOLE model captured in a hipGraph.  At a fixed budget every decode
@@ -221,10 +342,15 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
             self.pos = torch.full((1,), pos, dtype=torch.long, device=dev)
             self.graph = torch.cuda.CUDAGraph()
             plan.streaming = streaming
-            with torch.cuda.graph(self.graph):      # capture launches nothing: the first replay runs this step
-                cache.begin_forward(plan, self.pos)
-                self.logits = self_model(input_ids=self.tok, past_key_values=cache, position_ids=self.pos.view(1, -1),
-                                         use_cache=True).logits[:, -1, :]
+            self.cache = cache
+            tk = _ACTIVE.set(cache)
+            try:
+                with torch.cuda.graph(self.graph):      # capture launches nothing: the first replay runs this step
+                    cache.begin_forward(plan, self.pos)
+                    self.logits = self_model(input_ids=self.tok, past_key_values=cache, position_ids=self.pos.view(1, -1),
+                                             use_cache=True).logits[:, -1, :]
+            finally:
+                _ACTIVE.reset(tk)
 
         def __call__(self, tok, pos):
             self.tok.copy_(tok.view(1, 1))
@@ -236,15 +362,13 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
 
     # ---- single-token decode with eviction (decoding mode, and the tail of auto mode) ----------------------
     def decode_loop(cache, logits_last, cur_pos, score_off, budget_d, whole_cache):
-        out_ids: List[int] = []
+        log = TokenLog()
         positions: List[int] = []
-        n = 0
         graphed, prev_sig = None, None
-        while n < max_new_tokens:                               # :257 / :670
+        while log.n < max_new_tokens:                           # :257 / :670
             tok = sample(logits_last)
-            out_ids.append(int(tok[0, 0]))
-            n += 1
-            if out_ids[-1] in eos_token_ids:
+            log.push(tok)
+            if log.poll():
                 break
             t_now = cache.get_seq_length() + 1
             evict = evicting and (whole_cache or (t_now - score_off) > budget_d)     # :303 / every step :708
@@ -271,7 +395,8 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                 logits_last = forward(cache, tok.view(1, 1), [cur_pos], plan).logits[:, -1, :]
             prev_sig = sig
             cur_pos += 1
-        return out_ids
+        cache.host_syncs, cache.tokens_sampled = log.syncs, log.n
+        return log.ids(), log.fed
 
     # ---- dense prefix + strided chunks with eviction (encoding, auto, ppl) ---------------------------------
     def prefill(cache, budget_p, idx, r_idx, tova_head_mean, keep_logits=False):
@@ -312,8 +437,8 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
         out = forward(cache, input_ids, list(range(length)), StepPlan(policy="full", phase="prefill", accumulate=False))
         if evicting and scored:
             cache.bank.state_init(budget + 1, 0)                   # :242-245
-        out_ids = decode_loop(cache, out.logits[:, -1, :], length, length, budget, False)
-        kept = cache.get_seq_length() - length
+        out_ids, fed = decode_loop(cache, out.logits[:, -1, :], length, length, budget, False)
+        kept = min(fed, budget) if evicting else fed             # == cache length - prompt length when no forward ran past an EOS
         print(f"KV cache budget ratio: {kept / len(out_ids) * 100:.2f}%({kept}/{len(out_ids)})")
         result = self.tokenizer.decode(out_ids, skip_special_tokens=True).strip()
 
@@ -330,21 +455,25 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
             logits_last, _, _ = prefill(cache, budget_p, idx, r_idx, True)
         kept = cache.get_seq_length()
         print(f"KV cache budget ratio: {kept / length * 100:.2f}%({kept}/{length})")
-        out_ids, times, n, cur_pos = [], [], 0, length
-        while n < max_new_tokens:                                  # :508-526 plain decode, no eviction
+        log, cur_pos, t_first, n_fwd = TokenLog(), length, None, 0
+        while log.n < max_new_tokens:                              # :508-526 plain decode, no eviction
             tok = sample(logits_last)
-            out_ids.append(int(tok[0, 0]))
-            n += 1
-            if out_ids[-1] in eos_token_ids:
+            log.push(tok)
+            if log.poll():
                 break
-            t0 = time.time()
             logits_last = forward(cache, tok.view(1, 1), [cur_pos],
                                   StepPlan(policy="full", phase="decode", accumulate=False)).logits[:, -1, :]
-            times.append(time.time() - t0)
+            n_fwd += 1
+            if report_decoding_latency and n_fwd == 1:             # the reference drops the first step from the mean (:527)
+                torch.cuda.synchronize(dev)
+                t_first = time.time()
             cur_pos += 1
+        out_ids = log.ids()
+        cache.host_syncs, cache.tokens_sampled = log.syncs, log.n
         result = self.tokenizer.decode(out_ids, skip_special_tokens=True).strip()
-        if report_decoding_latency and len(times) > 1:
-            print(f"Per-step decoding latency: {statistics.mean(times[1:]):.3f}")
+        if report_decoding_latency and n_fwd > 1:
+            torch.cuda.synchronize(dev)
+            print(f"Per-step decoding latency: {(time.time() - t_first) / (n_fwd - 1):.3f}")
 
     elif kv_mode == "encoding_decoding":                          # :530-753
         assert type(budget) == int and budget <= length
@@ -355,28 +484,34 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
         cache = new_cache(idx + stride + 1)
         logits_last, _, _ = prefill(cache, budget_p, idx, r_idx, False)
         # the score rows keep their first idx+1 columns (:666-669); the decode rules then run over the whole cache
-        out_ids = decode_loop(cache, logits_last, length, 0, budget_p, True)
+        out_ids, _ = decode_loop(cache, logits_last, length, 0, budget_p, True)
         size = cache.get_seq_length()
         print(f"KV Cache Budget ratio {size / (length + len(out_ids)) * 100:.2f}%[{size}/({length}+{len(out_ids)})]")
         result = self.tokenizer.decode(out_ids, skip_special_tokens=True).strip()
 
     elif kv_mode == "ppl":                                        # :754-901
         ce = torch.nn.CrossEntropyLoss(reduction="none")
+        has_logits = shard is None or shard.rank == last_rank     # sharded: the logits exist on the last stage only
         if budget >= 1.0:     # NB: like the reference, ANY int budget takes this branch (:759); pass a ratio to evict
             cache = new_cache(length)
             out = forward(cache, input_ids, list(range(length)), StepPlan(policy="full", phase="prefill", accumulate=False))
-            lp = ce(out.logits[0, :-1].float(), input_ids[0, 1:]).cpu().numpy().tolist()
-            result = math.exp(statistics.mean(lp))
+            if has_logits:
+                lp = ce(out.logits[0, :-1].float(), input_ids[0, 1:]).cpu().numpy().tolist()
+                result = math.exp(statistics.mean(lp))
         else:
             budget_p, idx, r_idx = geometry("ppl", length, budget, stride)
             cache = new_cache(idx + stride if evicting else length)
-            _, all_logits, all_ids = prefill(cache, budget_p, idx, r_idx, True, keep_logits=True)
+            _, all_logits, all_ids = prefill(cache, budget_p, idx, r_idx, True, keep_logits=has_logits)
             kept = cache.get_seq_length()
             print(f"KV cache budget ratio: {kept / length * 100:.2f}%({kept}/{length})")
-            ids_cat, log_cat = torch.cat(all_ids), torch.cat(all_logits, dim=0)
-            assert ids_cat.shape[0] == log_cat.shape[0]
-            lp = ce(log_cat[:-1].float(), ids_cat[1:]).cpu().numpy().tolist()
-            result = math.exp(statistics.mean(lp))
+            if has_logits:
+                ids_cat, log_cat = torch.cat(all_ids), torch.cat(all_logits, dim=0)
+                assert ids_cat.shape[0] == log_cat.shape[0]
+                lp = ce(log_cat[:-1].float(), ids_cat[1:]).cpu().numpy().tolist()
+                result = math.exp(statistics.mean(lp))
+        if shard is not None:
+            from . import dist as DS
+            result = DS.broadcast_object(result, last_rank)
     else:
         raise ValueError(f"unknown kv_mode {kv_mode!r}")
     return (result, cache) if return_cache else result

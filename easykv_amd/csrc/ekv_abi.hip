@@ -92,6 +92,42 @@ __global__ void __launch_bounds__(256) ekv_compact_inplace_kernel(__half* k, __h
   }
 }
 
+// EKV_POLICY_RANGE ('recency' / 'random', easykv/easykv.py:343-362, :491-499, :105-112): every head of every layer drops the
+// same contiguous positions [start, start + k).  Nothing is scored, so nothing needs LDS-resident rows: only the slot map is
+// compacted — entries behind the range move down by k, the victims' rows become the free tail [T - k, T) — whatever the cache
+// length.  One workgroup per (head, layer); chunks ascend and every chunk is read completely before it is written, and a
+// chunk's sources lie at or beyond the next chunk's destinations, so no entry is overwritten before it has moved.
+__global__ void __launch_bounds__(256) ekv_range_evict_kernel(int32_t* slot_of_pos, int32_t* evict_ids, int n_kv_heads, int cap,
+                                                              int layer_begin, int T, int start, int k) {
+  extern __shared__ int32_t s_vict[];
+  const int h = blockIdx.x, ll = blockIdx.y, tid = threadIdx.x;
+  int32_t* map = slot_of_pos + ((size_t)(layer_begin + ll) * n_kv_heads + h) * cap;
+  for (int i = tid; i < k; i += 256) {
+    s_vict[i] = map[start + i];
+    if (evict_ids != nullptr) evict_ids[((size_t)ll * n_kv_heads + h) * k + i] = start + i;
+  }
+  __syncthreads();
+  constexpr int CH = 8;
+  for (int d0 = start; d0 < T - k; d0 += 256 * CH) {
+    int32_t buf[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) buf[c] = map[min(d0 + c * 256 + tid + k, T - 1)];   // unconditional (clamped) loads
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int d = d0 + c * 256 + tid;
+      if (d < T - k) map[d] = buf[c];
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < k; i += 256) map[T - k + i] = s_vict[i];
+}
+
+// A launch failure must be reported as THIS call's, not as whatever sticky-free error an earlier, unrelated runtime call of the
+// thread left behind: every entry point drops the stale last-error state first, then reads it back after its own launches.
+inline void drop_stale_error() { (void)hipGetLastError(); }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH; }
+
 int check_bank(const ekv_bank* b) {
   if (!b || !b->k || !b->v || !b->slot_of_pos) return EKV_E_ARG;
   if (b->n_layers <= 0 || b->n_kv_heads <= 0 || b->n_q_heads % b->n_kv_heads || b->cap <= 0) return EKV_E_ARG;
@@ -221,10 +257,11 @@ int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, in
 
 int ekv_bank_reset(const ekv_bank* bank, void* stream) {
   if (int e = check_bank(bank)) return e;
+  drop_stale_error();
   const size_t rows = (size_t)bank->n_layers * bank->n_kv_heads;
   hipLaunchKernelGGL(ekv_iota_rows_kernel, dim3((bank->cap + 255) / 256, (unsigned)rows), dim3(256), 0,
                      static_cast<hipStream_t>(stream), bank->slot_of_pos, bank->cap, rows);
-  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+  return launch_status();
 }
 
 int ekv_state_init(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t width, int32_t mode,
@@ -234,10 +271,11 @@ int ekv_state_init(const ekv_bank* bank, int32_t layer_begin, int32_t layer_coun
   if (!bank->score_sum || !bank->score_sq || !bank->score_cnt || width < 0 || width > bank->cap || mode < 0 || mode > 2)
     return EKV_E_ARG;
   const size_t row0 = (size_t)layer_begin * bank->n_kv_heads;
+  drop_stale_error();
   hipLaunchKernelGGL(ekv_state_init_kernel, dim3((bank->cap + 255) / 256, layer_count * bank->n_kv_heads), dim3(256), 0,
                      static_cast<hipStream_t>(stream), bank->score_sum, bank->score_sq, bank->score_cnt, bank->cap, width,
                      mode, stride, row0);
-  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+  return launch_status();
 }
 
 int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, const void* k_new, const void* v_new,
@@ -340,6 +378,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   sa.count_add = st->count_add;
   sa.count_tail_step = st->count_tail_step;
 
+  drop_stale_error();
   // whole decode step in one launch when no head has to be split
   if (n == 1 && st->phases == 0 && ws.n_split == 1 &&
       ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, aa.l_pad, st->n_evict, bank->cap, ws.fused_nw)) {
@@ -358,27 +397,46 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
                           rep * n <= 64 && !(st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) &&
                           ekv_score_lds_bytes_nt256(sa) <= 64 * 1024 && st->n_split != -1;
   if (fuse_chunk) sa.skip_fold = 1;
+
+  // How the step ends, decided BEFORE anything is launched: a shape no scorer can take must be refused while the bank is
+  // still untouched (the attention kernel appends the new rows).
+  //   fold_only  nothing to score and nothing to evict ('full', any unknown policy string), or phases = attention + fold
+  //   range_only 'recency' / 'random': no score rows at all, only the slot map is compacted — any cache length
+  const bool wants_scorer = ph == 0 || (ph & (2 | 8));
+  const bool fold_only = (!scored && st->n_evict == 0) || !wants_scorer;
+  const bool range_only = wants_scorer && st->policy == EKV_POLICY_RANGE;
+  const bool fast_scorer = wants_scorer && !fold_only && !range_only && !fuse_chunk && ekv_decode_score_supported(sa);
+  if (wants_scorer && !fold_only && !range_only && !fuse_chunk && !fast_scorer && ekv_score_lds_bytes(sa) > 160 * 1024)
+    return EKV_E_UNSUPPORTED;   // scored rows wider than one CU's LDS (W > ~10 000): see DESIGN.md "size limits"
+  if (n == 1 ? !ekv_attn_decode_supported(bank->head_dim, rep) : !ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
+
   if (ph != 0 && !(ph & 1)) {
   } else if (n == 1) {
-    if (!ekv_attn_decode_supported(bank->head_dim, rep)) return EKV_E_UNSUPPORTED;
     err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
   } else {
-    if (!ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
     err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, ws.two_pass != 0, s, fuse_chunk ? &sa : nullptr);
   }
   if (err != hipSuccess) return EKV_E_LAUNCH;
   if (ph == 1 || fuse_chunk) return EKV_OK;
 
-  if ((ph & 4) || (!scored && st->n_evict == 0 && !(ph & 8))) {
-    // nothing to score and nothing to evict ('full', or any unknown policy string): the step is the partial fold only,
-    // whatever the cache length (and not even that when the attention kernel has already written the output)
-    if (!ws.fold_in_kernel && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
-    if (!(ph & 8)) return EKV_OK;
+  if ((ph & 4) || fold_only || range_only) {
+    // (not even the fold when the attention kernel has already written the output)
+    if (!(ph & 8) || (ph & 4)) {
+      if (!ws.fold_in_kernel && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+    }
+    if (fold_only) return EKV_OK;
+  }
+  if (range_only) {
+    if (st->n_evict > 0) {
+      hipLaunchKernelGGL(ekv_range_evict_kernel, dim3(bank->n_kv_heads, st->layer_count), dim3(256), (size_t)st->n_evict * 4, s,
+                         bank->slot_of_pos, evict_ids, bank->n_kv_heads, bank->cap, st->layer_begin, T, st->range_start, st->n_evict);
+      return launch_status();
+    }
+    return EKV_OK;
   }
   sa.skip_fold = ((ph & 8) || ws.fold_in_kernel) ? 1 : 0;
-  if (ekv_decode_score_supported(sa))   // decode steps: the fast scorer (same tail as the fused kernel)
+  if (fast_scorer)   // decode steps: the fast scorer (same tail as the fused kernel)
     return ekv_launch_decode_score(sa, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
-  if (ekv_score_lds_bytes(sa) > 160 * 1024) return EKV_E_UNSUPPORTED;
   if (st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) {
     if (ekv_launch_tova_headmean(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
   }
@@ -392,12 +450,13 @@ int ekv_gather_ordered(const ekv_bank* bank, int32_t layer_begin, int32_t layer_
   if (int e = check_layers(bank, layer_begin, layer_count)) return e;
   if (!k_out || !v_out || n_slots < 0 || n_slots > bank->cap) return EKV_E_ARG;
   if (n_slots == 0) return EKV_OK;
+  drop_stale_error();
   const int rpb = 256 / (bank->head_dim / 8);
-  hipLaunchKernelGGL((ekv_rows_copy_kernel<true>), dim3(std::min(64, (n_slots + rpb - 1) / rpb), bank->n_kv_heads, layer_count),
+  hipLaunchKernelGGL((ekv_rows_copy_kernel<true>), dim3((n_slots + rpb - 1) / rpb, bank->n_kv_heads, layer_count),
                      dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<__half*>(bank->k),
                      static_cast<__half*>(bank->v), bank->slot_of_pos, static_cast<__half*>(k_out),
                      static_cast<__half*>(v_out), bank->n_kv_heads, bank->cap, bank->head_dim, layer_begin, 0, n_slots);
-  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+  return launch_status();
 }
 
 int ekv_scatter_rows(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t pos_begin, int32_t n,
@@ -406,14 +465,15 @@ int ekv_scatter_rows(const ekv_bank* bank, int32_t layer_begin, int32_t layer_co
   if (int e = check_layers(bank, layer_begin, layer_count)) return e;
   if (!k_in || !v_in || pos_begin < 0 || n < 0 || pos_begin + n > bank->cap) return EKV_E_ARG;
   if (n == 0) return EKV_OK;
+  drop_stale_error();
   const int rpb = 256 / (bank->head_dim / 8);
-  hipLaunchKernelGGL((ekv_rows_copy_kernel<false>), dim3(std::min(64, (n + rpb - 1) / rpb), bank->n_kv_heads, layer_count),
+  hipLaunchKernelGGL((ekv_rows_copy_kernel<false>), dim3((n + rpb - 1) / rpb, bank->n_kv_heads, layer_count),
                      dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<__half*>(bank->k),
                      static_cast<__half*>(bank->v), bank->slot_of_pos,
                      const_cast<__half*>(static_cast<const __half*>(k_in)),
                      const_cast<__half*>(static_cast<const __half*>(v_in)), bank->n_kv_heads, bank->cap, bank->head_dim,
                      layer_begin, pos_begin, n);
-  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+  return launch_status();
 }
 
 int ekv_compact_inplace(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, int32_t n_evict,
@@ -421,10 +481,11 @@ int ekv_compact_inplace(const ekv_bank* bank, int32_t layer_begin, int32_t layer
   if (int e = check_bank(bank)) return e;
   if (int e = check_layers(bank, layer_begin, layer_count)) return e;
   if (!evict_ids || n_evict <= 0 || n_evict >= n_slots || n_slots > bank->cap) return EKV_E_ARG;
+  drop_stale_error();
   hipLaunchKernelGGL(ekv_compact_inplace_kernel, dim3(2, bank->n_kv_heads, layer_count), dim3(256), (size_t)n_evict * 4,
                      static_cast<hipStream_t>(stream), static_cast<__half*>(bank->k), static_cast<__half*>(bank->v),
                      evict_ids, bank->n_kv_heads, bank->cap, bank->head_dim, layer_begin, n_slots, n_evict);
-  return hipGetLastError() == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+  return launch_status();
 }
 
 }  // extern "C"

@@ -424,7 +424,10 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
     const int pv = off + victim;
     int32_t* map = sc.slot_of_pos + head_row;
     if (have_cells) {
-      // every thread still holds the map entries of its positions: nothing to read, no barrier
+      // every thread still holds the map entries of its positions: nothing to read.  Scored policies have passed block
+      // reductions since cell[] was loaded; 'recency' / 'random' have passed none, and a thread's store lands on the entry a
+      // neighbouring wave loads as its own cell: make sure every load has happened
+      if (sc.policy == EKV_POLICY_RANGE) __syncthreads();
 #pragma unroll
       for (int it = 0; it < ITEMS; ++it) {
         const int p = tid + it * NT;

@@ -83,6 +83,69 @@ def ring_handoff_async(send: torch.Tensor, recv: torch.Tensor, shard: LayerShard
     return list(dist.batch_isend_irecv(ops))
 
 
+def _needs_host_staging(t: torch.Tensor) -> bool:
+    """gloo moves device tensors for collectives but has no device-side send/recv: stage point-to-point payloads through
+    the host (tests on a 1-GPU box; RCCL — backend 'nccl' — sends device buffers over xGMI directly)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def send(t: torch.Tensor, dst: int):
+    dist.send(t.cpu() if _needs_host_staging(t) else t, dst)
+
+
+def recv(t: torch.Tensor, src: int):
+    if _needs_host_staging(t):
+        buf = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(buf, src)
+        t.copy_(buf)
+    else:
+        dist.recv(t, src)
+    return t
+
+
+def broadcast(t: torch.Tensor, src: int):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src)
+    return t
+
+
+def broadcast_object(obj, src: int):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src)
+    return box[0]
+
+
+class PipelineStage:
+    """The hand-off of a layer-sharded model: stage r receives the hidden state ``[1, n, hidden]`` of the
+    forward in flight from stage r-1, runs its own layer block, and sends the result to stage r+1 — one point-to-point
+    transfer per stage boundary and forward, nothing else crosses xGMI (K/V, slot maps and score rows stay with the layer).
+    The reference gets the same partition from accelerate's ``device_map='auto'`` hooks (test_passkey.py:25-35), which copy
+    the hidden state between devices — and every layer's probability matrix to one device (llama_patch.py:244-246)."""
+
+    def __init__(self, shard: LayerShard):
+        self.shard = shard
+
+    @property
+    def first(self) -> bool:
+        return self.shard.rank == 0
+
+    @property
+    def last(self) -> bool:
+        return self.shard.rank == self.shard.world - 1
+
+    def recv_hidden(self, like: torch.Tensor) -> torch.Tensor:
+        """Stage input: ``like`` itself on the first stage, else the previous stage's output (same shape / dtype)."""
+        if self.shard.world == 1 or self.first:
+            return like
+        return recv(torch.empty_like(like), self.shard.rank - 1)
+
+    def send_hidden(self, hidden: torch.Tensor):
+        if self.shard.world > 1 and not self.last:
+            send(hidden.contiguous(), self.shard.rank + 1)
+
+
 def barrier(device=None):
     if device is not None and device.type == "cuda":
         torch.cuda.synchronize(device)

@@ -22,7 +22,7 @@ _registered = False
 
 
 def _easykv_attention(module, query, key, value, attention_mask=None, dropout=0.0, scaling=None, **kwargs):
-    cache = api.BudgetedKVCache.current
+    cache = api.active_cache()
     if cache is None:
         raise RuntimeError("easykv_amd attention called outside easykv_generate(): no BudgetedKVCache is active")
     d = query.shape[-1]
@@ -33,28 +33,45 @@ def _easykv_attention(module, query, key, value, attention_mask=None, dropout=0.
         # true positions, so take it off again (rotation by -theta: x = x'*cos - rotate_half(x')*sin, fp32)
         if cache.unrotate is None or cache.positions is None:
             raise RuntimeError("streaming=True through the HF seam needs easykv_generate() to supply the rotary tables")
-        cos, sin = (t[cache.positions].to(torch.float32) for t in cache.unrotate)      # [n, D]
-        query, key = _unrotate(query, cos, sin), _unrotate(key, cos, sin)
+        cos, sin = (t[cache.positions].to(torch.float32) for t in cache.unrotate[:2])      # [n, D]
+        # the module rotated with cos*s, sin*s (s = attention_scaling: 1 except yarn / longrope): x' = s*R(x).  The kernel
+        # rotates with the PURE tables at read time, so the model's s^2 on the logits is put back on the query alone
+        s = float(cache.unrotate[2]) if len(cache.unrotate) > 2 else 1.0
+        query, key = _unrotate(query, cos, sin, s), _unrotate(key, cos, sin, 1.0 / s)
     out = cache.attend(module.layer_idx, query, key, value)        # [1, Hq, n, D] fp16
     return out.transpose(1, 2).to(query.dtype), None
 
 
-def _unrotate(x, cos, sin):
+def _unrotate(x, cos, sin, gain=1.0):
+    """Inverse of the PURE rotation (cos, sin) applied to x, times ``gain``."""
     xf = x.to(torch.float32)
     half = xf.shape[-1] // 2
     rot = torch.cat((-xf[..., half:], xf[..., :half]), dim=-1)      # rotate_half (llama_patch.py:13-17)
-    return (xf * cos - rot * sin).to(x.dtype)
+    out = xf * cos - rot * sin
+    return (out * gain if gain != 1.0 else out).to(x.dtype)
 
 
 def rope_tables_from_model(model, n_pos, head_dim, device):
-    """fp32 (cos, sin) ``[n_pos, head_dim]`` from the model's own rotary module (so rope_theta, DynamicNTK / linear
-    scaling and attention scaling are the model's), for the RoPE-on-read variant."""
+    """fp32 PURE rotation tables (cos, sin) ``[n_pos, head_dim]`` + the module's ``attention_scaling`` s, from the model's
+    own rotary module: cos/sin of ``outer(position, inv_freq)`` in the ``cat(freqs, freqs)`` layout — so rope_theta and
+    linear / llama3 / yarn frequency scaling are the model's, while s (yarn, longrope: the module multiplies its tables by
+    it) is kept apart: the un-rotation has to divide it out and the logits keep their s^2 through the query.
+    DynamicNTK recomputes ``inv_freq`` whenever the sequence outgrows ``max_seq_len_cached``: the tables are only the
+    inverse of what the model applied while that does not happen, so the base must be frozen first
+    (``set_dynamicntk_rope_length(model, max_len)``, easykv/utils.py:53-57) for sequences that long."""
     for sub in model.modules():
         if hasattr(sub, "inv_freq") and hasattr(sub, "rope_type"):
-            x = torch.zeros(1, 1, head_dim, dtype=torch.float32, device=device)
-            with torch.no_grad():
-                cos, sin = sub(x, torch.arange(n_pos, device=device).view(1, -1))
-            return cos[0].to(torch.float32).contiguous(), sin[0].to(torch.float32).contiguous()
+            if sub.rope_type == "dynamic" and n_pos > int(getattr(sub, "max_seq_len_cached", 0) or 0) + 64:
+                raise ValueError(f"streaming=True needs positions up to {n_pos} but the DynamicNTK rotary module would change its "
+                                 f"frequencies beyond {sub.max_seq_len_cached}: call set_dynamicntk_rope_length(model, max_length) first")
+            if sub.rope_type == "longrope":
+                raise ValueError("streaming=True is not supported with longrope (position-dependent frequency sets)")
+            inv_freq = sub.inv_freq.to(device=device, dtype=torch.float32)
+            if inv_freq.numel() * 2 != head_dim:
+                raise ValueError("partial rotary embeddings are not supported by the RoPE-on-read kernels")
+            freqs = torch.outer(torch.arange(n_pos, device=device, dtype=torch.float32), inv_freq)
+            emb = torch.cat((freqs, freqs), dim=-1)
+            return emb.cos().contiguous(), emb.sin().contiguous(), float(getattr(sub, "attention_scaling", 1.0) or 1.0)
     raise ValueError("no rotary embedding module found in this model")
 
 

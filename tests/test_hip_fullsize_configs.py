@@ -134,3 +134,18 @@ def test_config4_llama13b_heads_ppl_streaming_stride96_full_geometry():
     res, tr, frac = _run_pair("ppl", 96, cfg, 1, 40, 40, 128, 10253, seed=1313, min_stable=0.8)
     assert tr.cache_len == 4109
     assert abs(res - float(tr.result)) <= 1e-6 * abs(float(tr.result))
+
+
+def test_config3_vicuna_passkey_stride96_full_geometry():
+    """configs[3]: Vicuna-7B-16K passkey retrieval (/root/reference/test_passkey.py:38,53-64): a 9994-token prompt, encoding mode,
+    stride 96, budget 0.5, kv_policy roco -> budget'=5093, idx=5002, r_idx=4906 (README.md:205-214 prints
+    ``50.05%(5002/9994)``), Hq=H=32, D=128: the dense 4906-token causal prefix, then 53 chunk steps of 96 queries per head over a
+    cache oscillating 5002 <-> 5098 (easykv/easykv.py:367-503), then plain decode.  One layer (the per-layer work is
+    independent); the layer-sharded run of the same driver is tests/test_hip_sharded_generate.py."""
+    from easykv_amd import geometry
+    assert geometry("encoding", 9994, 0.5, 96) == (5093, 5002, 4906)
+    cfg = dict(budget=0.5, kv_policy="roco", max_new_tokens=3, temp_length=4, recent_ratio=0.1)
+    res, tr, frac = _run_pair("encoding", 96, cfg, 1, 32, 32, 128, 9994, seed=9994)
+    assert tr.report.strip() == "KV cache budget ratio: 50.05%(5002/9994)"
+    assert tr.cache_len == 5002 + 3
+    assert res == " ".join(str(t) for t in tr.result)

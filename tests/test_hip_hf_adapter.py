@@ -35,8 +35,7 @@ def test_full_budget_matches_hf_eager_logits_and_greedy_tokens():
     easykv_amd.enable_fixed_kv(model, _Tok(), mode="decoding", stride=1)
     # prefill through the chunk kernel: logits of the patched forward
     cache = easykv_amd.BudgetedKVCache(2, 4, 2, 32, 64, torch.device("cuda"))
-    cache.begin_forward(easykv_amd.StepPlan(policy="full", phase="prefill", accumulate=False))
-    with torch.inference_mode():
+    with torch.inference_mode(), cache.active(easykv_amd.StepPlan(policy="full", phase="prefill", accumulate=False)):
         got = model(input_ids=ids, past_key_values=cache, position_ids=torch.arange(40, device="cuda").view(1, -1), use_cache=True).logits.float()
     assert torch.allclose(got, ref_logits, atol=3e-2, rtol=3e-2), float((got - ref_logits).abs().max())
     # greedy decode with no eviction ('full'): same tokens as HF's own generate

@@ -106,3 +106,39 @@ def test_set_dynamicntk_rope_length_fixes_the_ntk_base():
         easykv_amd.set_dynamicntk_rope_length(torch.nn.Linear(2, 2), 128)
     with pytest.raises(NotImplementedError):
         easykv_amd.set_dynamicntk_rope_length(object(), 128)
+
+
+def test_integration_md_stub_structs_match_the_binding():
+    """The ctypes stub documented in INTEGRATION.md §3 (executed verbatim on the GPU by tests/test_hip_seam.py) declares
+    the same struct layouts and signatures as the product's own binding."""
+    import ctypes as C
+    import os
+    import re
+    from easykv_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text[text.index("## 3."):], re.S).group(1)
+    code = code.replace('"easykv_amd/csrc/libeasykv_hip.so"', repr(os.path.join(root, "easykv_amd", "csrc", "libeasykv_hip.so")))
+    ns = {}
+    exec(code.split("# one-time")[0], ns)
+    for theirs, ours in ((ns["ekv_bank"], _lib.Bank), (ns["ekv_step"], _lib.Step)):
+        assert C.sizeof(theirs) == C.sizeof(ours)
+        assert [(n, getattr(theirs, n).offset, getattr(theirs, n).size) for n, _ in theirs._fields_] == \
+               [(n, getattr(ours, n).offset, getattr(ours, n).size) for n, _ in ours._fields_]
+    lib = _lib.load()
+    assert [a for a in ns["lib"].ekv_step_attend.argtypes[2:]] == [a for a in lib.ekv_step_attend.argtypes[2:]]
+
+
+def test_active_cache_is_context_local():
+    """No process-wide 'current cache': the seam reads a context variable that generate() sets around each forward."""
+    import threading
+    from easykv_amd import api
+    assert api.active_cache() is None
+    tok = api._ACTIVE.set("mine")
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(api.active_cache()))
+    t.start()
+    t.join()
+    assert seen == [None] and api.active_cache() == "mine"
+    api._ACTIVE.reset(tok)
+    assert api.active_cache() is None
