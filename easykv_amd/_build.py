@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(CSRC, "libeasykv_hip.so")
+LIB = os.environ.get("EASYKV_HIP_LIB") or os.path.join(CSRC, "libeasykv_hip.so")   # (override: profiling builds)
 # -ffp-contract=off: the score arithmetic must round like the reference's separate torch ops
 # (q/c - (s/c)**2); FMAs that are wanted are written as fmaf()/dot2/MFMA explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -385,6 +385,11 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
     return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, ws.fused_nw, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
 
+  // small-row chunk step (configs[1]: stride 8): one launch, logits in LDS, K and V read once
+  if (n > 1 && ekv_chunk_lds_supported(bank, st, aa.phys_extent, scored) &&
+      (st->layer_count * bank->n_kv_heads >= 256 || T <= 1024))
+    return ekv_launch_chunk_lds(aa, sa, bank->head_dim, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+
   // phases: 0 = whole step; else a bit mask: 1 attention kernel, 2 scorer (fold + score), 4 fold only, 8 scorer
   // without the fold (4 and 8 let the caller run the scorer on a side stream, off the critical path)
   const int ph = st->phases;

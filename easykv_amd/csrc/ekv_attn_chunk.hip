@@ -76,3 +76,37 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
 #undef EKV_GO
   return e;
 }
+
+// ---- small-row chunk step with the logits in LDS (ekv_chunk_lds.inc) -------------------------------------------------------
+size_t ekv_chunk_lds_bytes_d32(int, int, int);
+size_t ekv_chunk_lds_bytes_d64(int, int, int);
+size_t ekv_chunk_lds_bytes_d128(int, int, int);
+hipError_t ekv_launch_chunk_lds_d32(const EkvAttnArgs&, const EkvScoreArgs&, int, hipStream_t);
+hipError_t ekv_launch_chunk_lds_d64(const EkvAttnArgs&, const EkvScoreArgs&, int, hipStream_t);
+hipError_t ekv_launch_chunk_lds_d128(const EkvAttnArgs&, const EkvScoreArgs&, int, hipStream_t);
+
+// Eligible: a scored, accumulating chunk step (plain keys, score rows over the whole cache) with at most 8 GQA-folded query
+// rows whose logits fit LDS next to a second workgroup of the CU (<= 80 KB), one victim set per head.
+bool ekv_chunk_lds_supported(const ekv_bank* bank, const ekv_step* st, int phys_extent, bool scored) {
+  const int rep = bank->n_q_heads / bank->n_kv_heads;
+  if (st->q_len < 2 || rep * st->q_len > 8 || (rep & (rep - 1)) != 0 || !scored || !st->accumulate || st->rope_on_read || st->score_off != 0) return false;
+  if (st->phases != 0 || st->n_split == -1 || st->two_pass != 0 || !st->causal) return false;   // (two_pass = -1: "exported logits")
+  if (st->policy == EKV_POLICY_TOVA && st->tova_head_mean) return false;   // needs every head of the layer first
+  if (st->n_slots > 10 * 256 || st->n_evict >= st->n_slots || st->n_evict > 16) return false;
+  size_t lds = 1u << 30;
+  switch (bank->head_dim) {
+    case 32: lds = ekv_chunk_lds_bytes_d32(rep * st->q_len, phys_extent, st->n_slots); break;
+    case 64: lds = ekv_chunk_lds_bytes_d64(rep * st->q_len, phys_extent, st->n_slots); break;
+    case 128: lds = ekv_chunk_lds_bytes_d128(rep * st->q_len, phys_extent, st->n_slots); break;
+  }
+  return lds <= 80 * 1024;
+}
+
+hipError_t ekv_launch_chunk_lds(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, hipStream_t s) {
+  switch (head_dim) {
+    case 32: return ekv_launch_chunk_lds_d32(a, sc, layer_count, s);
+    case 64: return ekv_launch_chunk_lds_d64(a, sc, layer_count, s);
+    case 128: return ekv_launch_chunk_lds_d128(a, sc, layer_count, s);
+  }
+  return hipErrorInvalidValue;
+}

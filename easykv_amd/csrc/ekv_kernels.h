@@ -91,3 +91,7 @@ size_t ekv_score_lds_bytes(const EkvScoreArgs& a);
 bool ekv_decode_score_supported(const EkvScoreArgs& sc);
 hipError_t ekv_launch_decode_score(const EkvScoreArgs& sc, int layer_count, hipStream_t s);
 hipError_t ekv_launch_fold(const EkvScoreArgs& sc, int layer_count, hipStream_t s);
+
+// Small-row chunk step with the logits in LDS (ekv_chunk_lds.inc): whole step in one launch, K and V read once.
+bool ekv_chunk_lds_supported(const ekv_bank* bank, const ekv_step* st, int phys_extent, bool scored);
+hipError_t ekv_launch_chunk_lds(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, hipStream_t s);

@@ -1,0 +1,18 @@
+"""Chunk-phase timing of one Bench-P shape (bench.strided_prefill): python tools/bench_chunk.py [S] [stride] [n_chunks] [kv_heads]"""
+import json
+import os
+import sys
+import types
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+stride = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+n_chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 48
+kvh = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+args = types.SimpleNamespace(layers=32, heads=32, kv_heads=kvh, head_dim=128, policy=os.environ.get("POLICY", "roco"), identity_layout=False)
+r = bench.strided_prefill(args, torch.device("cuda"), n_chunks=n_chunks, S=S, stride=stride)
+print(json.dumps({k: r[k] for k in ("workload", "us_per_chunk_step", "frac_of_hbm_peak", "as_two_launches_us", "value")}))
