@@ -140,7 +140,9 @@ def test_phase_split_and_side_stream_scorer_equal_the_whole_step(n, hq, h):
     if n == 1:
         kw = dict(policy="roco", phase="decode", evict=True, budget=t0, n_split=2)
     else:
-        kw = dict(policy="roco", phase="prefill", accumulate=True, evict=True, budget=t0 + n, recent=30, sink=4, stride=n)
+        # two_pass=-1: every mode on the MFMA chunk kernel (whole small-row steps would otherwise take the logits-in-LDS kernel,
+        # which is compared with this path in tests/test_hip_random_shapes.py — within tolerance, not bit for bit)
+        kw = dict(policy="roco", phase="prefill", accumulate=True, evict=True, budget=t0 + n, recent=30, sink=4, stride=n, two_pass=-1)
     res = {}
     for mode in ("whole", "phases", "overlap"):
         bank = KVBank(2, hq, h, d, cap=t0 + n)
