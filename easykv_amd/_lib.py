@@ -30,7 +30,7 @@ class Step(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "layer_begin", "layer_count", "q_len", "n_slots", "score_off", "policy", "accumulate", "n_evict",
         "win_lo", "win_tail", "roco_k1", "roco_tail", "range_start", "tova_head_mean", "causal", "rope_on_read",
-        "n_split", "phases")] + [(n, C.c_float) for n in ("count_add", "count_tail_step", "sm_div")] + [("two_pass", C.c_int32), ("phys_extent", C.c_int32)]
+        "n_split", "phases")] + [(n, C.c_float) for n in ("count_add", "count_tail_step", "sm_div")] + [("two_pass", C.c_int32), ("phys_extent", C.c_int32), ("defer_layers", C.c_int32), ("defer_index", C.c_int32)]
 
 
 class EkvError(RuntimeError):
@@ -67,7 +67,7 @@ def load():
     lib.ekv_compact_inplace.argtypes = [C.POINTER(Bank), i32, i32, i32, i32, vp, vp]
     for name in EXPORTS[3:]:
         getattr(lib, name).restype = C.c_int
-    if lib.ekv_abi_version() != 2:
+    if lib.ekv_abi_version() != 3:
         raise EkvError("ABI version mismatch")
     _lib = lib
     return lib

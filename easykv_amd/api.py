@@ -161,6 +161,15 @@ class BudgetedKVCache:
                                         v[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), layer_begin=layer_idx)
                 outs.append(o)
             return torch.cat(outs, dim=2)
+        if n == 1 and plan.phase == "decode" and self.layer_count > 1:
+            # one layer per call (a decoder stack): attention + fold of this layer now, the scorers of all owned layers in ONE
+            # launch after the last layer (KVBank.flush) — off the critical path of the stack
+            out, _ = self.bank.attend(plan, q, k, v, layer_begin=layer_idx, defer=True)
+            if self.n_attend == self.layer_count:
+                ids = self.bank.flush()
+                if self._cur is not None and ids is not None:
+                    self._cur.extend(ids[l] for l in range(self.layer_count))
+            return out
         out, ids = self.bank.attend(plan, q, k, v, layer_begin=layer_idx)
         if self._cur is not None and ids is not None:
             self._cur.append(ids[0])

@@ -239,9 +239,17 @@ const char* ekv_strerror(int code) {
   }
 }
 
+// Deferred scorer (ekv_step.defer_layers): the workspace is laid out for all deferred layers whatever this call launches
+static ekv_step defer_layout_step(const ekv_step* st) {
+  ekv_step full = *st;
+  if (st->defer_layers > 0) full.layer_count = st->defer_layers;
+  return full;
+}
+
 size_t ekv_workspace_bytes(const ekv_bank* bank, const ekv_step* step) {
   if (!bank || !step) return 0;
-  return ekv_plan_workspace(bank, step, nullptr).bytes;
+  const ekv_step full = defer_layout_step(step);
+  return ekv_plan_workspace(bank, &full, nullptr).bytes;
 }
 
 int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, int32_t* fused) {
@@ -302,8 +310,20 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
       return EKV_E_ARG;
   }
   const int rep = bank->n_q_heads / bank->n_kv_heads;
-  const EkvWs ws = ekv_plan_workspace(bank, st, workspace);
+  if (st->defer_layers != 0) {   // deferred scorer: decode steps, explicit splits, attention + fold now / scorer later
+    if (st->defer_layers < 0 || st->defer_index < 0 || st->defer_index + st->layer_count > st->defer_layers || n != 1 || st->n_split <= 0 ||
+        (st->phases != (1 | 4) && st->phases != 8))
+      return EKV_E_ARG;
+  }
+  const ekv_step layout = defer_layout_step(st);
+  EkvWs ws = ekv_plan_workspace(bank, &layout, workspace);
   if (ws.bytes > workspace_bytes) return EKV_E_WORKSPACE;
+  if (st->defer_layers > 0) {    // this call's slice of the per-layer arrays
+    const size_t rows0 = (size_t)st->defer_index * bank->n_q_heads * n;
+    if (ws.logits) ws.logits += rows0 * ws.t_pad;
+    ws.partials += rows0 * ws.n_partials * (bank->head_dim + 2);
+    ws.tova_row += (size_t)st->defer_index * ws.t_pad;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   EkvAttnArgs aa{};

@@ -76,6 +76,7 @@ class KVBank:
         self._ws_free = []
         self._ring_pos = 0
         self._score_done = [None] * n_layers
+        self._defer = None      # deferred-scorer state of the token step in flight (attend(..., defer=True) ... flush())
         self._bank = Bank(self.k.data_ptr(), self.v.data_ptr(), self.slot_of_pos.data_ptr(),
                           self.score_sum.data_ptr() if scored else None, self.score_sq.data_ptr() if scored else None,
                           self.score_cnt.data_ptr() if scored else None, n_layers, n_q_heads, n_kv_heads, head_dim, cap)
@@ -223,9 +224,73 @@ class KVBank:
         for l in range(layer_begin, layer_begin + lc):
             self._score_done[l] = done
 
-    def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None, phases=0, overlap_scorer=False):
+    # -- one layer per call (a real decoder stack): attention now, scoring / eviction once per token ------------------------
+    def _attend_deferred(self, plan: StepPlan, q, k_new, v_new, layer, out):
+        """Decode step of ONE layer with the scorer deferred (ekv_step.defer_layers): attention + fold of this layer now — its
+        output is what the next layer waits for — and one scorer launch over all layers of the bank at :meth:`flush`, instead
+        of a 15 us latency-bound scorer kernel on the critical path of every layer."""
+        d = self._defer
+        t = self.n_slots[layer] + 1
+        if d is None or d["plan"] is not plan or d["t"] != t:
+            if d is not None and d["pending"]:
+                raise _lib.EkvError("attend(defer=True): the previous token step was not flushed")
+            st = self.make_step(plan, 1, 0, 1)
+            if plan.n_split <= 0:      # the split count of a one-layer launch, fixed for both halves of the step
+                st.phases = 1
+                ns, fu = C.c_int32(0), C.c_int32(0)
+                check(self.lib.ekv_step_plan(C.byref(self._bank), C.byref(st), C.byref(ns), C.byref(fu)), "ekv_step_plan")
+                st.n_split = ns.value
+            st.defer_layers = self.n_layers
+            need = self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st))
+            ids = torch.empty(self.n_layers, self.n_kv_heads, 1, dtype=torch.int32, device=self.device) if st.n_evict > 0 else None
+            ws = self._workspace(need)
+            # everything that is the same for all layers of the token step is resolved once: the per-layer call below is on the
+            # critical path of the decoder stack (host cost per layer ~ GPU cost per layer in this regime)
+            d = self._defer = dict(plan=plan, t=t, st=st, ws=ws, ids=ids, pending=0, rope=(_ptr(self.rope_cos), _ptr(self.rope_sin)),
+                                   st_ref=C.byref(st), bank_ref=C.byref(self._bank), ws_ptr=ws.data_ptr(), ws_len=ws.numel(),
+                                   stream=self._stream(), call=self.lib.ekv_step_attend)
+        st = d["st"]
+        st.layer_begin = st.defer_index = layer
+        st.layer_count, st.phases = 1, 5
+        ext = self.extent[layer]
+        st.phys_extent = ext if ext > t else t
+        if out is None:
+            out = torch.empty(1, self.n_q_heads, 1, self.head_dim, dtype=torch.float16, device=self.device)
+        rc = d["call"](d["bank_ref"], d["st_ref"], q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(), out.data_ptr(), None,
+                       d["rope"][0], d["rope"][1], d["ws_ptr"], d["ws_len"], d["stream"])
+        if rc != 0:
+            check(rc, "ekv_step_attend")
+        self.extent[layer] = st.phys_extent
+        d["pending"] += 1
+        return out
+
+    def flush(self):
+        """Scorer of every layer of the token step opened by ``attend(..., defer=True)``: accumulate, select, compact — one
+        launch.  Returns the evicted positions ``[layers, H, 1]`` (or None)."""
+        d = self._defer
+        if d is None or d["pending"] == 0:
+            return None
+        if d["pending"] != self.n_layers:
+            raise _lib.EkvError(f"flush(): {d['pending']} of {self.n_layers} layers attended in this token step")
+        st, ws = d["st"], d["ws"]
+        st.layer_begin, st.layer_count, st.defer_index, st.phases = 0, self.n_layers, 0, 8
+        st.phys_extent = max(max(self.extent), d["t"])
+        check(self.lib.ekv_step_attend(C.byref(self._bank), C.byref(st), ws.data_ptr(), ws.data_ptr(), ws.data_ptr(), ws.data_ptr(),
+                                       _ptr(d["ids"]), d["rope"][0], d["rope"][1], ws.data_ptr(), ws.numel(), d["stream"]), "ekv_step_attend")
+        for l in range(self.n_layers):
+            self.n_slots[l] = d["t"] - st.n_evict
+        d["pending"] = 0
+        d["t"] = -1
+        return d["ids"] if st.n_evict > 0 else None
+
+    def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None, phases=0, overlap_scorer=False, defer=False):
         """q ``[layers, Hq, n, D]``, k_new/v_new ``[layers, H, n, D]`` (fp16, device).
-        Returns (out ``[layers, Hq, n, D]`` fp16, evict_ids ``[layers, H, k]`` int32 or None)."""
+        Returns (out ``[layers, Hq, n, D]`` fp16, evict_ids ``[layers, H, k]`` int32 or None).
+        ``defer=True`` (one layer, q_len 1): attention + fold only; the scorers of all layers run at :meth:`flush`."""
+        if defer:
+            if q.shape[0] != 1 or q.shape[2] != 1 or phases != 0:
+                raise ValueError("defer=True is for one-layer decode calls")
+            return self._attend_deferred(plan, q, k_new, v_new, layer_begin, out), None
         lc, _, n, _ = q.shape
         st = self.make_step(plan, n, layer_begin, lc)
         st.phases = phases

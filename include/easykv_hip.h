@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EKV_ABI_VERSION 2
+#define EKV_ABI_VERSION 3
 
 /* kv_policy strings of the reference -> codes (easykv/easykv.py:288-300, :310-362) */
 enum {
@@ -101,6 +101,14 @@ typedef struct ekv_step {
                            masks the dead ones, so a tight E saves reading free rows.  With the free list kept as this
                            library keeps it (freed rows first, then never-used rows ascending) E is simply the high-water
                            mark of n_slots.                                                                          */
+  int32_t defer_layers; /* > 0: DEFERRED SCORER for a model that issues one layer per call (a real decoder stack: layer l + 1's
+                           query depends on layer l's output, easykv/easykv.py:264-269).  The attention output of a layer is
+                           needed at once, its scoring / eviction only before the NEXT token: the per-layer call (q_len = 1,
+                           phases = 1|4: attention + fold) leaves its logits and partials in slice `defer_index` of a workspace laid
+                           out for `defer_layers` layers, and ONE call with phases = 8 over all those layers
+                           (layer_count = defer_layers, defer_index = 0) scores and evicts for the whole token.  Both calls must
+                           pass the same explicit n_split and the same workspace.  0 = off.                               */
+  int32_t defer_index;  /* slice of this call's first layer in the deferred workspace                                      */
 } ekv_step;
 
 int ekv_abi_version(void);

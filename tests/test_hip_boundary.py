@@ -170,3 +170,47 @@ def test_phase_split_and_side_stream_scorer_equal_the_whole_step(n, hq, h):
     for mode in ("phases", "overlap"):
         for a, b in zip(res["whole"], res[mode]):
             assert torch.equal(a, b), mode
+
+
+@pytest.mark.parametrize("policy,hq,h,stream", [("roco", 8, 8, False), ("h2o_head", 8, 2, False), ("tova", 4, 4, True), ("recency", 4, 4, False)])
+def test_deferred_scorer_per_layer_calls_equal_the_whole_step(policy, hq, h, stream):
+    """ekv_step.defer_layers: one attention + fold call per layer (what a decoder stack issues) and ONE scorer launch for all
+    layers at the end of the token == the whole step of every layer, bit for bit: outputs, evicted ids, score rows, slot maps."""
+    from easykv_amd import KVBank, StepPlan
+    from easykv_amd.api import rope_tables
+    L, d, t0, steps = 4, 64, 260, 7
+    g = torch.Generator().manual_seed(hq * 10 + h)
+    k0, v0 = torch.randn(L, h, t0, d, generator=g).half().cuda(), torch.randn(L, h, t0, d, generator=g).half().cuda()
+    qs = [torch.randn(L, hq, 1, d, generator=g).half().cuda() for _ in range(steps)]
+    ks = [torch.randn(L, h, 1, d, generator=g).half().cuda() for _ in range(steps)]
+    vs = [torch.randn(L, h, 1, d, generator=g).half().cuda() for _ in range(steps)]
+    res = {}
+    for mode in ("whole", "deferred"):
+        bank = KVBank(L, hq, h, d, cap=t0 + 1)
+        if stream:
+            bank.set_rope(*rope_tables(bank.cap + 8, d))
+        bank.load_rows(k0, v0)
+        bank.state_init(t0 + 1, 0)
+        outs, idl = [], []
+        for i in range(steps):
+            plan = StepPlan(policy=policy, phase="decode", evict=True, budget=t0, n_split=3, streaming=stream,
+                            accumulate=policy != "recency", range_start=5 if policy == "recency" else -1)
+            if mode == "whole":
+                out = torch.empty(L, hq, 1, d, dtype=torch.float16, device="cuda")
+                ids = torch.full((L, h, 1), -1, dtype=torch.int32, device="cuda")
+                for l in range(L):
+                    o, ii = bank.attend(plan, qs[i][l:l + 1], ks[i][l:l + 1], vs[i][l:l + 1], layer_begin=l, out=out[l:l + 1], evict_ids=ids[l:l + 1])
+            else:
+                out = torch.empty(L, hq, 1, d, dtype=torch.float16, device="cuda")
+                for l in range(L):
+                    bank.attend(plan, qs[i][l:l + 1], ks[i][l:l + 1], vs[i][l:l + 1], layer_begin=l, out=out[l:l + 1], defer=True)
+                    assert bank.n_slots[l] == t0          # nothing is evicted before the flush
+                ids = bank.flush().clone()
+            assert bank.n_slots == [t0] * L
+            outs.append(out)
+            idl.append(ids)
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(outs), torch.stack(idl), bank.slot_of_pos.clone(), bank.score_sum.clone(), list(bank.n_slots))
+    for a, b in zip(res["whole"][:4], res["deferred"][:4]):
+        assert torch.equal(a, b)
+    assert res["whole"][4] == res["deferred"][4]

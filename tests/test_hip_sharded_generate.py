@@ -112,5 +112,7 @@ def test_two_rank_layer_sharded_generate_equals_one_rank_and_reference(two_rank_
     for f, (a, b, ref) in enumerate(zip(r0["outs"], r1["outs"], ref_out)):
         both = torch.from_numpy(np.concatenate((a, b), axis=0))
         assert torch.allclose(both, ref, rtol=OUT_TOL / 2, atol=OUT_TOL), f
-        assert np.array_equal(both.numpy(), one["outs"][f]), f           # same kernels, same inputs: bit-identical
-        assert np.array_equal(r1["hidden"][f], one["hidden"][f]), f      # rank 1 continued rank 0's running sum
+        # (a rank that owns ONE layer runs whole fused steps, the 1-rank run defers the scorers of its layers: same values up to
+        # the split count of the partial fold)
+        assert np.allclose(both.numpy(), one["outs"][f], rtol=OUT_TOL / 2, atol=OUT_TOL), f
+        assert np.allclose(r1["hidden"][f], one["hidden"][f], rtol=1e-3, atol=2e-3), f      # rank 1 continued rank 0's running sum

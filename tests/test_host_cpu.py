@@ -40,7 +40,7 @@ def test_abi_exports_every_declared_symbol():
     raw = ctypes.CDLL(_build.LIB)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.ekv_abi_version() == 2
+    assert lib.ekv_abi_version() == 3
     assert b"workspace" in lib.ekv_strerror(-3)
     # argument checking happens before any device access: callable without a GPU
     assert lib.ekv_workspace_bytes(None, None) == 0
@@ -50,7 +50,7 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from easykv_amd._lib import Bank, Step
     assert ctypes.sizeof(Bank) == 6 * 8 + 5 * 4 + 4      # 6 pointers, 5 int32, tail padding
-    assert ctypes.sizeof(Step) == 18 * 4 + 5 * 4
+    assert ctypes.sizeof(Step) == 18 * 4 + 5 * 4 + 2 * 4
     header = open(os.path.join(ROOT, "include", "easykv_hip.h")).read()
     body = header[header.index("typedef struct ekv_step {"):header.index("} ekv_step;")]
     names = re.findall(r"\b([a-z_0-9]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))

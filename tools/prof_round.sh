@@ -1,0 +1,30 @@
+#!/bin/bash
+# Evidence run of a round on the GPU box (called through gpurun): rocprofv3 kernel trace of the default bench command, then
+# FETCH_SIZE / WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md: they do not fit one pass; never combined with a trace)
+# for the decode bench and for each strided-prefill shape.  Raw outputs -> gpurun_out/prof_$TAG; tools/summarize_prof.py
+# condenses them into profiles/${TAG}_*.
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+run_pmc() {   # name, counter, command...
+  local name=$1 ctr=$2; shift 2
+  rm -rf /tmp/p_$name
+  timeout 300 rocprofv3 --pmc $ctr --output-format csv -d /tmp/p_$name -- "$@" > $OUT/${name}.log 2>&1
+  mkdir -p $OUT/$name
+  cp $(find /tmp/p_$name -name "*counter_collection.csv" | head -1) $OUT/$name/ 2>/dev/null
+}
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- python $R/bench.py --steps 512 --no-cpu-baseline > $OUT/bench_under_trace.log 2>&1
+mkdir -p $OUT/trace; cp $(find /tmp/p_trace -name "*kernel_stats.csv" | head -1) $OUT/trace/
+D="python $R/bench.py --no-cpu-baseline --steps 16 --warmup 4 --prewarm-s 0.05 --no-prefill --no-boundary"
+run_pmc decode_fetch FETCH_SIZE $D
+run_pmc decode_write WRITE_SIZE $D
+for cfg in "c2 4096 8 24" "s64 4096 64 12" "c4 9994 96 8"; do
+  set -- $cfg
+  run_pmc chunk_$1_fetch FETCH_SIZE python $R/tools/bench_chunk.py $2 $3 $4
+  run_pmc chunk_$1_write WRITE_SIZE python $R/tools/bench_chunk.py $2 $3 $4
+done
+cd $R
+python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+ls $OUT
