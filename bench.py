@@ -205,7 +205,7 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
     ev[1].record()
     torch.cuda.synchronize(dev)
     t_step = ev[0].elapsed_time(ev[1]) / n_chunks * 1e-3
-    one_launch = bool(bank.step_plan(plan, stride)[0] == 1)
+    one_launch = bool(bank.step_plan(plan, stride)[0] == 1 and Hq // H * stride <= 64)
     # ... and the same step as two launches (attention kernel, then fold + score + select + compaction), for the breakdown
     ev2 = []
     for i in range(warm + 8):
@@ -224,13 +224,41 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
     T = idx + stride
     n_state = {"roco": 3, "h2o_head": 1, "tova": 1}[plan.policy]
     by = algorithmic_bytes(H, Hq, D, T, stride, n_state)
+    traffic, traffic_src = prefill_pmc(S, stride, L, Hq, H, D, plan.policy)
+    gbs = by["total"] * L / t_step / 1e9
     return {"workload": f"bench-P chunk phase: S={S} stride={stride} budget=0.5 -> idx={idx}, T={T}, L={L} Hq={Hq} H={H} D={D} kv_policy={plan.policy}",
             "value": stride / t_step, "unit": "prompt tokens/s (chunk phase, attention/eviction path only)",
-            "us_per_chunk_step": t_step * 1e6, "one_launch_fused_scorer": one_launch,
+            "us_per_chunk_step": t_step * 1e6, "one_launch": one_launch,
             "as_two_launches_us": {"attn_kernel": t_attn * 1e6, "score_select": t_score * 1e6},
-            "algorithmic_bytes_per_step": by["total"] * L, "achieved_gbs": by["total"] * L / t_step / 1e9,
-            "frac_of_hbm_peak": by["total"] * L / t_step / 1e9 / HBM_PEAK_GBS, "chunk_steps_timed": n_chunks,
-            "slot_map": "identity" if args.identity_layout else "scattered"}
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "bytes_per_step": by["total"] * L, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic": (traffic / (by["total"] * L)) if traffic else None,
+                         "timing": "one HIP event pair around the timed chunk steps / steps (launches back to back)"},
+            "chunk_steps_timed": n_chunks, "slot_map": "identity" if args.identity_layout else "scattered"}
+
+
+def prefill_pmc(S, stride, L, Hq, H, D, policy):
+    """HBM bytes per whole chunk step from the newest rocprofv3 PMC summary under profiles/ (tools/prof_round.sh +
+    tools/summarize_prof.py: FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE): the kernels one step launches."""
+    import glob
+    import re
+    stem = {(4096, 8): "c2", (4096, 64): "s64", (9994, 96): "c4"}.get((S, stride))
+    if stem is None or (L, Hq, H, D, policy) != (32, 32, 32, 128, "roco"):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_prefill_summary.json")),
+                   key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    for f in reversed(files):
+        try:
+            ks = json.load(open(f))[stem]["kernels"]
+        except Exception:
+            continue
+        one = [v for n, v in ks.items() if "ekv_chunk_lds_kernel" in n or ("ekv_attn_chunk_kernel" in n and "true>" in n)]
+        if one:       # the whole step is one launch
+            return one[0]["hbm_bytes_per_launch"], f"profiles/{os.path.basename(f)} [{stem}]: one launch per step"
+        two = [v for n, v in ks.items() if "ekv_attn_chunk_kernel" in n or "ekv_score_select_kernel" in n]
+        if two:
+            return sum(v["hbm_bytes_per_launch"] for v in two), f"profiles/{os.path.basename(f)} [{stem}]: attention kernel + scorer kernel"
+    return None, None
 
 
 def boundary_kernels(args, dev, iters=6):

@@ -15,4 +15,5 @@ n_chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 48
 kvh = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 args = types.SimpleNamespace(layers=32, heads=32, kv_heads=kvh, head_dim=128, policy=os.environ.get("POLICY", "roco"), identity_layout=False)
 r = bench.strided_prefill(args, torch.device("cuda"), n_chunks=n_chunks, S=S, stride=stride)
-print(json.dumps({k: r[k] for k in ("workload", "us_per_chunk_step", "frac_of_hbm_peak", "as_two_launches_us", "value")}))
+print(json.dumps({"workload": r["workload"], "us_per_chunk_step": r["us_per_chunk_step"], "frac_of_hbm_peak": r["roofline"]["frac"],
+                  "as_two_launches_us": r["as_two_launches_us"], "value": r["value"]}))

@@ -1,51 +1,94 @@
 #!/usr/bin/env python
-"""Condense a rocprofv3 run (gpurun_out/<dir>/{trace,pmc_fetch,pmc_write}) into profiles/<tag>_*.
+"""Condense a tools/prof_round.sh run (gpurun_out/prof_<tag>/...) into profiles/<tag>_*.
 
-    python tools/summarize_prof.py gpurun_out/prof2 r01_decode
+    python tools/summarize_prof.py gpurun_out/prof_r02 r02
 
-HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB... on gfx950 FETCH_SIZE reports
-exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so it is doubled; WRITE_SIZE is taken as is.
-"""
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the default bench command, ekv_* kernels),
+profiles/<tag>_decode_summary.json (fused decode kernel: trace + PMC) and profiles/<tag>_prefill_summary.json (per chunk
+shape: kernel durations from the PMC runs' timestamps + PMC bytes).
+
+HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies
+the 128-byte requests of a wide coalesced streaming read (16 B per lane) at 64 bytes — exactly half — so it is doubled;
+WRITE_SIZE is taken as is; the two counters are collected in separate passes and never together with a trace."""
 import csv
+import glob
 import json
 import os
 import sys
 
 
-def main(src, tag):
+def pmc_per_kernel(d, key):
+    files = glob.glob(os.path.join(d, "*counter_collection.csv"))
+    per = {}
+    if not files:
+        return per
+    for r in csv.DictReader(open(files[0])):
+        if "ekv_" in r["Kernel_Name"] and r["Counter_Name"] == key:
+            e = per.setdefault(r["Kernel_Name"], dict(v=[], dur=[], lds=int(r["LDS_Block_Size"]), vgpr=int(r["VGPR_Count"]),
+                                                      wg=int(r["Workgroup_Size"]), grid=int(r["Grid_Size"])))
+            e["v"].append(float(r["Counter_Value"]))
+            e["dur"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return per
+
+
+def combine(src, stem, skip_first=2):
+    f, w = pmc_per_kernel(os.path.join(src, stem + "_fetch"), "FETCH_SIZE"), pmc_per_kernel(os.path.join(src, stem + "_write"), "WRITE_SIZE")
     out = {}
-    stats = os.path.join(src, "trace", [f for f in os.listdir(os.path.join(src, "trace")) if f.endswith("kernel_stats.csv")][0])
-    rows = list(csv.DictReader(open(stats)))
+    for k in f:
+        fv, wv = f[k]["v"][skip_first:] or f[k]["v"], (w.get(k, {}).get("v") or [0.0])
+        wv = wv[skip_first:] or wv
+        fetch, write = sum(fv) / len(fv), sum(wv) / len(wv)
+        dur = f[k]["dur"][skip_first:] or f[k]["dur"]
+        out[k] = dict(launches=len(f[k]["v"]), FETCH_SIZE_KiB_avg=fetch, WRITE_SIZE_KiB_avg=write,
+                      hbm_bytes_per_launch=(2.0 * fetch + write) * 1024.0,
+                      correction="2 x FETCH_SIZE (gfx950 wide coalesced reads tallied at half) + WRITE_SIZE, KiB -> bytes",
+                      avg_us_under_pmc=sum(dur) / len(dur), workgroup_size=f[k]["wg"], lds_bytes=f[k]["lds"], vgprs=f[k]["vgpr"])
+    return out
+
+
+def main(src, tag):
     os.makedirs("profiles", exist_ok=True)
-    with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
-        w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-        for r in rows:
-            if "ekv_" in r["Name"]:
-                w.writerow([r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
-                out.setdefault("kernels", {})[r["Name"]] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
-                                                               min_us=float(r["MinNs"]) / 1e3, max_us=float(r["MaxNs"]) / 1e3)
-    for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        d = os.path.join(src, name)
-        if not os.path.isdir(d):
-            continue
-        f = os.path.join(d, [x for x in os.listdir(d) if x.endswith("counter_collection.csv")][0])
-        per = {}
-        for r in csv.DictReader(open(f)):
-            if "ekv_" in r["Kernel_Name"] and r["Counter_Name"] == key:
-                per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-        for k, v in per.items():
-            out.setdefault("pmc", {}).setdefault(k, {})[key + "_KiB_avg"] = sum(v) / len(v)
-            out["pmc"][k]["VGPR_SGPR_note"] = "see counter_collection.csv columns VGPR_Count / SGPR_Count"
-    for k, v in out.get("pmc", {}).items():
-        if "FETCH_SIZE_KiB_avg" in v and "WRITE_SIZE_KiB_avg" in v:
-            v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE_KiB_avg"] + v["WRITE_SIZE_KiB_avg"]) * 1024.0
-            v["correction"] = "2 x FETCH_SIZE (gfx950 wide coalesced reads tallied at half) + WRITE_SIZE, KiB -> bytes"
-    bj = os.path.join(src, "bench_trace.json")
-    if os.path.exists(bj) and os.path.getsize(bj):
-        out["bench_line_under_rocprof"] = json.loads(open(bj).read().strip().splitlines()[-1])
-    json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
-    print(json.dumps(out.get("pmc", {}), indent=1)[:1500])
+    stats = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
+    kernels = {}
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        with open(f"profiles/{tag}_kernel_stats.csv", "w") as fo:
+            w = csv.writer(fo)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                if "ekv_" in r["Name"]:
+                    w.writerow([r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
+                    kernels[r["Name"]] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, min_us=float(r["MinNs"]) / 1e3,
+                                              max_us=float(r["MaxNs"]) / 1e3)
+    dec = dict(command="rocprofv3 --kernel-trace --stats -- python bench.py --steps 512 --no-cpu-baseline ; rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE "
+                       "-- python bench.py --no-cpu-baseline --steps 16 --warmup 4 --prewarm-s 0.05 --no-prefill --no-boundary",
+               kernels=kernels, pmc=combine(src, "decode"))
+    bl = os.path.join(src, "bench_line.json")
+    if os.path.exists(bl) and os.path.getsize(bl):
+        dec["bench_line_same_box"] = json.loads(open(bl).read().strip().splitlines()[-1])
+    json.dump(dec, open(f"profiles/{tag}_decode_summary.json", "w"), indent=1)
+    pre = {}
+    algo = dict(c2=("S=4096 stride=8 budget=0.5 (configs[1]): T=2064", 35663872 * 32), s64=("S=4096 stride=64: T=2176", None),
+                c4=("S=9994 stride=96 budget=0.5 (configs[3] shape): T=5098", None))
+    for stem, (desc, _) in algo.items():
+        c = combine(src, "chunk_" + stem)
+        if c:
+            log = os.path.join(src, f"chunk_{stem}_fetch.log")
+            line = None
+            if os.path.exists(log):
+                for ln in open(log):
+                    if ln.startswith("{"):
+                        line = json.loads(ln)
+            pre[stem] = dict(shape=desc, command=f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python tools/bench_chunk.py ...", kernels=c, bench_chunk_line=line)
+            if line:
+                ab = None
+                for k, v in c.items():
+                    if "chunk" in k and v["launches"] >= 8:
+                        ab = v
+                pre[stem]["note"] = "algorithmic bytes per step = algorithmic_bytes_per_step of bench.py (SURVEY.md §8d W_step x 32 layers)"
+    json.dump(pre, open(f"profiles/{tag}_prefill_summary.json", "w"), indent=1)
+    for name, d in (("decode", dec["pmc"]), ("prefill", {k: {kk: vv["hbm_bytes_per_launch"] for kk, vv in v["kernels"].items()} for k, v in pre.items()})):
+        print(name, json.dumps(d, indent=1)[:1800])
 
 
 if __name__ == "__main__":
