@@ -129,10 +129,19 @@ def run_reference(E, core, case, streams):
     cfg = dict(case["config"], eos_token_ids=[-1])
     ids = torch.arange(case["length"]).view(1, -1) % 16
     buf = io.StringIO()
+    orig_multinomial = torch.multinomial
+    if "rng_seed" in case:
+        # kv_policy='random' draws its victim from the GLOBAL CPU generator (easykv/easykv.py:354, :495), which the reference's
+        # sampler (torch.multinomial on the CPU, :130) shares.  The fixture pins the policy's own draws: the sampler is made
+        # draw-free for this run (the logits are one-hot, multinomial == argmax) and the generator is seeded, so the recorded
+        # ranges are a pure function of the seed and of the reference's torch.rand call sequence.
+        torch.multinomial = lambda p, num_samples=1, **kw: p.argmax(dim=-1, keepdim=True)
+        torch.manual_seed(case["rng_seed"])
     try:
         with contextlib.redirect_stdout(buf), cuda_to_cpu_shim():
             res = E.generate(self=model, input_ids=ids, generation_config=cfg, kv_mode=case["mode"], stride=case["stride"])
     finally:
+        torch.multinomial = orig_multinomial
         E.truncate_kv_cache_silo, E.truncate_kv_cache_liso, E.truncate_kv_cache = orig
     return model, log, res, buf.getvalue().strip()
 
@@ -177,6 +186,8 @@ def run_oracle(case, streams):
     model = FakeAttnModel(qs, ks, vs, arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False))
     cfg = dict(case["config"], eos_token_ids=[-1])
     ids = torch.arange(case["length"]).view(1, -1) % 16
+    if "rng_seed" in case:
+        torch.manual_seed(case["rng_seed"])
     tr = O.generate(model, ids, cfg, kv_mode=case["mode"], stride=case["stride"])
     return model, tr
 
@@ -198,6 +209,9 @@ def cases():
     r3 = dict(recent_ratio=0.3)
     for pol in ("roco", "h2o_head", "tova", "recency"):
         add(f"dec_{pol}", mode="decoding", length=16, config=dict(budget=40, kv_policy=pol, max_new_tokens=90))
+    # kv_policy='random' (easykv/easykv.py:353-357, :494-499): seeded CPU generator, see run_reference
+    add("dec_random", mode="decoding", length=16, rng_seed=20240, config=dict(budget=40, kv_policy="random", max_new_tokens=90))
+    add("enc_random_s4", mode="encoding", stride=4, length=100, rng_seed=20241, config=dict(budget=0.5, kv_policy="random", max_new_tokens=4))
     add("dec_roco_ties", mode="decoding", length=16, config=dict(budget=24, kv_policy="roco", max_new_tokens=60))
     add("dec_full", mode="decoding", length=16, config=dict(budget=24, kv_policy="full", max_new_tokens=30))
     add("dec_unknown_policy", mode="decoding", length=16, config=dict(budget=24, kv_policy="h2o", max_new_tokens=30))
@@ -302,7 +316,7 @@ def main():
         max_do = max((float((a - b).abs().max()) for a, b in zip(outs, omodel.outputs_log)), default=0.0)
         meta = dict(name=case["name"], mode=case["mode"], stride=case["stride"], length=case["length"], dims=d,
                     config=case["config"], seed=case["seed"], arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False),
-                    printed=printed, result=(res if isinstance(res, float) else str(res)), n_forwards=len(outs),
+                    printed=printed, result=(res if isinstance(res, float) else str(res)), n_forwards=len(outs), rng_seed=case.get("rng_seed"),
                     tie_free=probe.unstable == 0, n_selections=probe.n, n_unstable=probe.unstable)
         np.savez_compressed(os.path.join(OUT, case["name"] + ".npz"), meta=json.dumps(meta),
                             qs=streams[0].numpy(), ks=streams[1].numpy(), vs=streams[2].numpy(),

@@ -18,6 +18,8 @@ def test_oracle_reproduces_reference(name):
     model = FakeAttnModel(qs, ks, vs, arch=m["arch"], streaming=m["streaming"])
     cfg = dict(m["config"], eos_token_ids=[-1])
     ids = torch.arange(m["length"]).view(1, -1) % 16
+    if m.get("rng_seed") is not None:      # kv_policy='random': the reference's draws come from the seeded global CPU generator
+        torch.manual_seed(m["rng_seed"])
     tr = O.generate(model, ids, cfg, kv_mode=m["mode"], stride=m["stride"])
     kinds, ph, rg = trace_events(tr)
     assert np.array_equal(kinds, g["kinds"])
