@@ -117,3 +117,73 @@ def test_two_rank_pipelined_async_handoff():
         assert p.exitcode == 0
     assert res[0] == [100.0 + i for i in range(steps)]     # rank 0 receives rank 1's values
     assert res[1] == [0.0 + i for i in range(steps)]
+
+
+def _worker_sharded_oracle(rank, world, port, out_q):
+    """The host logic of the layer-sharded driver (LayerShard + PipelineStage + token broadcast) with the CPU oracle as the
+    per-layer engine (test infrastructure; the product's engine is the HIP KVBank, see tests/test_hip_sharded_generate.py)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from easykv_amd import dist as D
+    from oracle import easykv_oracle as O
+    from tests.golden_util import load_golden
+    r, _, w = D.init("gloo")
+    g = load_golden("dec_roco")
+    m = g["meta"]
+    qs, ks, vs = (x.float() for x in g["streams"])
+    L, H = m["dims"]["L"], m["dims"]["H"]
+    P, budget = m["length"], m["config"]["budget"]
+    shard = D.LayerShard(r, w, L)
+    stage = D.PipelineStage(shard)
+    states = {}
+    for l in range(shard.begin, shard.end):
+        st = O.LayerState(k=ks[l][:, :P].unsqueeze(0), v=vs[l][:, :P].unsqueeze(0))
+        st.s, st.q, st.c = O.init_state_decoding((H,), budget)
+        states[l] = st
+    ids_log, hid_log, toks = [], [], []
+    for step in range(m["config"]["max_new_tokens"]):
+        t = P + step
+        hidden = stage.recv_hidden(torch.zeros(1, 1, qs.shape[1] * qs.shape[3]))
+        for l in range(shard.begin, shard.end):
+            st = states[l]
+            gen = st.k.shape[2] + 1 - P
+            plan = O.StepPlan(policy="roco", phase="decode", evict=gen > budget, score_off=P, budget=budget)
+            o, ids = O.layer_step(st, qs[l][:, t:t + 1].unsqueeze(0), ks[l][:, t:t + 1].unsqueeze(0), vs[l][:, t:t + 1].unsqueeze(0), plan)
+            hidden = hidden + o[0].transpose(0, 1).reshape(1, 1, -1)
+            if ids is not None:
+                ids_log.append((step, l, (ids + P).flatten().tolist()))
+        stage.send_hidden(hidden)
+        tok = torch.tensor([[step % 7]]) if stage.last else torch.zeros(1, 1, dtype=torch.long)   # "sampled" on the last stage only
+        toks.append(int(D.broadcast(tok, w - 1)[0, 0]))
+        hid_log.append(float(hidden.sum()))
+    out_q.put((r, shard.begin, shard.end, ids_log, hid_log, toks))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_layer_sharded_driver_logic_matches_the_reference_golden():
+    """Two gloo ranks, one layer block each: per-rank layer state, hidden-state hand-off, token broadcast from the last stage.
+    The evicted ids of every layer equal the reference's golden vector; the last stage sees the full-depth hidden state."""
+    import numpy as np
+    from tests.golden_util import load_golden, split_ids
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded_oracle, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = load_golden("dec_roco")
+    ref = split_ids(g)                       # per evicting step: [L, H, 1]
+    (r0, b0, e0, ids0, hid0, tok0), (r1, b1, e1, ids1, hid1, tok1) = res
+    assert (b0, e0, b1, e1) == (0, 1, 1, 2)
+    first = min(s for s, _, _ in ids0)
+    for log in (ids0, ids1):
+        for step, l, ids in log:
+            assert np.array_equal(np.asarray(ids, dtype=np.int32), ref[step - first][l].flatten()), (step, l)
+    assert len(ids0) == len(ids1) == len(ref)
+    assert tok0 == tok1 == [s % 7 for s in range(len(tok0))]     # every rank continues with the last stage's token
+    assert all(abs(a) > 0 for a in hid1) and hid0 != hid1         # rank 1 continued rank 0's running sum
