@@ -96,3 +96,53 @@ def patch_model(model):
         if sub_cfg is not None and hasattr(sub_cfg, "_attn_implementation"):
             sub_cfg._attn_implementation = IMPL
     return model
+
+
+class _SkippedLayer(torch.nn.Module):
+    """Stands in for a decoder layer another rank owns: the hidden state passes through untouched."""
+
+    def forward(self, hidden_states, *args, **kwargs):
+        return hidden_states
+
+
+def shard_model(model, shard):
+    """Layer-shard a stock HF Llama / Mistral decoder stack over the ranks of ``shard`` (easykv_amd.dist.LayerShard): this
+    process keeps the decoder layers ``[shard.begin, shard.end)`` — their weights, and through ``easykv_generate`` their K/V
+    banks — drops the others, receives the hidden state of every forward from the previous stage in front of its first layer and
+    sends it to the next stage behind its last one (one point-to-point transfer per stage boundary and forward, RCCL over xGMI
+    with backend ``nccl``).  Embedding, final norm and lm_head stay on every rank; only the last stage's logits are meaningful and
+    ``easykv_generate`` samples there and broadcasts the token.
+
+    The reference gets this partition from accelerate's ``device_map='auto'`` (test_passkey.py:25-35, test_ppl.py:25-38), whose
+    hooks copy the hidden state between devices — and every layer's probability matrix to one device (llama_patch.py:244-246)."""
+    from .dist import PipelineStage
+    layers = None
+    for sub in model.modules():
+        cand = getattr(sub, "layers", None)
+        if isinstance(cand, torch.nn.ModuleList) and len(cand) == model.config.num_hidden_layers:
+            layers = cand
+            break
+    if layers is None:
+        raise ValueError("no decoder stack (a ModuleList `layers` of config.num_hidden_layers modules) found in this model")
+    if shard.n_layers != len(layers):
+        raise ValueError(f"shard covers {shard.n_layers} layers, the model has {len(layers)}")
+    stage = PipelineStage(shard)
+    for l in range(len(layers)):
+        if not (shard.begin <= l < shard.end):
+            layers[l] = _SkippedLayer()
+    if shard.world > 1 and shard.count > 0:
+        def recv_hook(module, args, kwargs):
+            if stage.first:
+                return None
+            hidden = args[0] if args else kwargs["hidden_states"]
+            got = stage.recv_hidden(hidden)
+            return ((got,) + tuple(args[1:]), kwargs) if args else (args, dict(kwargs, hidden_states=got))
+
+        def send_hook(module, args, kwargs, output):
+            stage.send_hidden(output[0] if isinstance(output, tuple) else output)
+            return output
+
+        layers[shard.begin].register_forward_pre_hook(recv_hook, with_kwargs=True)
+        layers[shard.end - 1].register_forward_hook(send_hook, with_kwargs=True)
+    model.layer_shard = shard
+    return model

@@ -116,3 +116,67 @@ def test_two_rank_layer_sharded_generate_equals_one_rank_and_reference(two_rank_
         # the split count of the partial fold)
         assert np.allclose(both.numpy(), one["outs"][f], rtol=OUT_TOL / 2, atol=OUT_TOL), f
         assert np.allclose(r1["hidden"][f], one["hidden"][f], rtol=1e-3, atol=2e-3), f      # rank 1 continued rank 0's running sum
+
+
+def _tiny_llama(seed=0):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(seed)
+    cfg = LlamaConfig(vocab_size=97, hidden_size=128, intermediate_size=256, num_hidden_layers=4, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=32, max_position_embeddings=512, attn_implementation="eager")
+    return LlamaForCausalLM(cfg).half().cuda().eval()
+
+
+class _Tok:
+    eos_token_id = -1
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(i) for i in ids)
+
+
+def _hf_run(shard):
+    import easykv_amd
+    from easykv_amd import hf
+    model = hf.patch_model(_tiny_llama(3))
+    if shard is not None:
+        hf.shard_model(model, shard)
+    ids = (torch.arange(150) * 7 % 97).view(1, -1).cuda()
+    out = {}
+    for mode, stride, cfg in (("decoding", 1, dict(budget=40, kv_policy="roco", max_new_tokens=60)),
+                              ("auto", 8, dict(budget=64, kv_policy="roco", max_new_tokens=12, recent_ratio=0.3))):
+        easykv_amd.enable_fixed_kv(model, _Tok(), mode=mode, stride=stride)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            text = model.easykv_generate(input_ids=ids[:, :24] if mode == "decoding" else ids,
+                                         generation_config=dict(cfg, temperature=1e-6, eos_token_ids=[-1]))
+        out[mode] = (text, buf.getvalue().strip().splitlines()[-1])
+    return out
+
+
+def _hf_worker(rank, world, port, out_q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from easykv_amd import dist as D
+    r, _, w = D.init("gloo")
+    torch.cuda.set_device(0)
+    res = _hf_run(D.LayerShard(r, w, 4))
+    out_q.put((r, res))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_hf_llama_layer_sharded_over_two_ranks_generates_the_same_tokens():
+    """easykv_amd.hf.shard_model on a stock HF Llama (4 layers, GQA): two ranks own two decoder layers each, the hidden state
+    crosses the stage boundary on every forward, the last stage samples.  Greedy tokens and the printed budget line equal the
+    1-rank run in decoding and auto mode (budgeted cache, roco)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hf_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    one = _hf_run(None)
+    for mode in ("decoding", "auto"):
+        assert got[0][mode] == got[1][mode] == one[mode], (mode, got[0][mode], one[mode])
