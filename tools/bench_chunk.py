@@ -8,6 +8,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from easykv_amd.engine import KVBank  # noqa: E402
+
+KVBank.default_two_pass = int(os.environ.get("TWO_PASS", "0"))   # 1: force the two-pass chunk kernels, -1: exported logits
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 stride = int(sys.argv[2]) if len(sys.argv) > 2 else 8
