@@ -18,11 +18,11 @@ import sys
 
 
 def pmc_per_kernel(d, key):
-    files = glob.glob(os.path.join(d, "*counter_collection.csv"))
+    files = sorted(glob.glob(os.path.join(d, "*counter_collection.csv")), key=os.path.getmtime)    # newest run of this directory
     per = {}
     if not files:
         return per
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(files[-1])):
         if "ekv_" in r["Kernel_Name"] and r["Counter_Name"] == key:
             e = per.setdefault(r["Kernel_Name"], dict(v=[], dur=[], lds=int(r["LDS_Block_Size"]), vgpr=int(r["VGPR_Count"]),
                                                       wg=int(r["Workgroup_Size"]), grid=int(r["Grid_Size"])))
@@ -48,10 +48,10 @@ def combine(src, stem, skip_first=2):
 
 def main(src, tag):
     os.makedirs("profiles", exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")), key=os.path.getmtime)
     kernels = {}
     if stats:
-        rows = list(csv.DictReader(open(stats[0])))
+        rows = list(csv.DictReader(open(stats[-1])))
         with open(f"profiles/{tag}_kernel_stats.csv", "w") as fo:
             w = csv.writer(fo)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
