@@ -23,7 +23,7 @@ class Bank(C.Structure):
     _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("slot_of_pos", C.c_void_p),
                 ("score_sum", C.c_void_p), ("score_sq", C.c_void_p), ("score_cnt", C.c_void_p),
                 ("n_layers", C.c_int32), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32),
-                ("head_dim", C.c_int32), ("cap", C.c_int32)]
+                ("head_dim", C.c_int32), ("cap", C.c_int32), ("arrive", C.c_void_p)]
 
 
 class Step(C.Structure):

@@ -269,6 +269,7 @@ int ekv_bank_reset(const ekv_bank* bank, void* stream) {
   const size_t rows = (size_t)bank->n_layers * bank->n_kv_heads;
   hipLaunchKernelGGL(ekv_iota_rows_kernel, dim3((bank->cap + 255) / 256, (unsigned)rows), dim3(256), 0,
                      static_cast<hipStream_t>(stream), bank->slot_of_pos, bank->cap, rows);
+  if (bank->arrive != nullptr && hipMemsetAsync(bank->arrive, 0, rows * 4, static_cast<hipStream_t>(stream)) != hipSuccess) return EKV_E_LAUNCH;
   return launch_status();
 }
 
@@ -435,6 +436,14 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
     return EKV_E_UNSUPPORTED;   // scored rows wider than one CU's LDS (W > ~10 000): see DESIGN.md "size limits"
   if (n == 1 ? !ekv_attn_decode_supported(bank->head_dim, rep) : !ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
 
+  // decode split path whose partials are folded right behind the attention kernel (attention + fold phases, or a step that has
+  // nothing to score): the last-arriving split of a head folds them inside the attention kernel — no fold launch
+  const bool fold_in_decode = n == 1 && bank->arrive != nullptr && (ph == 0 || (ph & 1)) && !ws.fold_in_kernel &&
+                              ((ph & 4) || (ph == 0 && (fold_only || range_only)));
+  if (fold_in_decode) {
+    aa.arrive = bank->arrive + (size_t)st->layer_begin * bank->n_kv_heads;
+    aa.out_direct = static_cast<__half*>(out);
+  }
   if (ph != 0 && !(ph & 1)) {
   } else if (n == 1) {
     err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
@@ -447,7 +456,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   if ((ph & 4) || fold_only || range_only) {
     // (not even the fold when the attention kernel has already written the output)
     if (!(ph & 8) || (ph & 4)) {
-      if (!ws.fold_in_kernel && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+      if (!ws.fold_in_kernel && !fold_in_decode && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
     }
     if (fold_only) return EKV_OK;
   }

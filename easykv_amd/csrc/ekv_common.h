@@ -128,6 +128,55 @@ __device__ __forceinline__ float ekv_fold_partials_auto(const float* p0, int n_s
   return ekv_fold_partials_auto<MAXB>(p0, n_split, PS, d, mm, ls);
 }
 
+// Agent-scope store of a partial that ANOTHER workgroup of the same launch will read (global_store ... sc1: written through to the
+// memory side, where the reader's sc1 loads find it).
+__device__ __forceinline__ void ekv_store_sc1(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The same fold over partials written by OTHER workgroups of the same launch (in-kernel fold by the last-arriving split): the
+// loads are buffer loads with the sc1 cache policy (agent scope: served by memory-side caches, never by this CU's L1 or a stale
+// line) from a wave-UNIFORM descriptor + per-lane offsets, so a batch still goes out as one round trip.  (__hip_atomic_load is
+// issued one load at a time with a wait behind each: 51 serialised round trips made the fold cost 25 us; a descriptor built
+// from a per-lane pointer makes hipcc wrap every load in a waterfall loop.)  Arithmetic identical to ekv_fold_partials.
+template <int BATCH>
+__device__ __forceinline__ float ekv_fold_partials_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned row_off, int n_split, int PS, int d) {
+  float mm = EKV_NEG_INF, ls = 0.f, os = 0.f;
+  for (int s0 = 0; s0 < n_split; s0 += BATCH) {
+    float mv[BATCH], lv[BATCH], ov[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const bool ok = s0 + i < n_split;
+      const unsigned off = (row_off + (unsigned)(ok ? s0 + i : 0) * (unsigned)PS) * 4u;
+      const float pm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 16));
+      const float pl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4u, 0, 16));
+      const float po = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 8u + 4u * (unsigned)d, 0, 16));
+      mv[i] = ok ? pm : EKV_NEG_INF;
+      lv[i] = ok ? pl : 0.f;
+      ov[i] = ok ? po : 0.f;
+    }
+    float mb = mm;
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) mb = fmaxf(mb, mv[i]);
+    const float rescale = (mm == EKV_NEG_INF) ? 0.f : exp2f((mm - mb) * EKV_LOG2E);
+    ls *= rescale;
+    os *= rescale;
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const float w = (mv[i] == EKV_NEG_INF) ? 0.f : exp2f((mv[i] - mb) * EKV_LOG2E);
+      ls += lv[i] * w;
+      os += ov[i] * w;
+    }
+    mm = mb;
+  }
+  return os / ls;
+}
+__device__ __forceinline__ float ekv_fold_partials_buf_auto(__amdgpu_buffer_rsrc_t rsrc, unsigned row_off, int n_split, int PS, int d) {
+  if (n_split <= 8) return ekv_fold_partials_buf<8>(rsrc, row_off, n_split, PS, d);       // (same batch choice as
+  if (n_split <= 16 || n_split > 24) return ekv_fold_partials_buf<16>(rsrc, row_off, n_split, PS, d);   //  ekv_fold_partials_auto<16>)
+  return ekv_fold_partials_buf<24>(rsrc, row_off, n_split, PS, d);
+}
+
 // Barrier that only orders LDS traffic: global loads of the next super-tile stay in flight across it
 // (__syncthreads() would drain vmcnt(0) whenever a global store may be pending).
 __device__ __forceinline__ void ekv_lds_barrier() {

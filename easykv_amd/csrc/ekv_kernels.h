@@ -48,6 +48,8 @@ struct EkvAttnArgs {
   int32_t qb_rows, n_qblocks;  // chunk kernels: queries per query block, number of query blocks
   int32_t phys_extent;         // fused decode step, physical-order stream: live rows have physical index < phys_extent
   int32_t l_pad;               // fused decode step: pitch of a logits row in LDS (t_pad, or align(phys_extent, 64))
+  uint32_t* arrive;            // split decode kernel: non-null = fold the key-range partials in the kernel (last-arriving split of a
+                               //   head) and write the fp16 output to out_direct; the bank's counters [n_layers][H], 0 when idle
   float sm_div;
 };
 

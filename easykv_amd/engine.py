@@ -77,9 +77,11 @@ class KVBank:
         self._ring_pos = 0
         self._score_done = [None] * n_layers
         self._defer = None      # deferred-scorer state of the token step in flight (attend(..., defer=True) ... flush())
+        self.arrive = torch.zeros(n_layers, n_kv_heads, dtype=torch.int32, device=dev)     # arrival counters of the in-kernel fold
         self._bank = Bank(self.k.data_ptr(), self.v.data_ptr(), self.slot_of_pos.data_ptr(),
                           self.score_sum.data_ptr() if scored else None, self.score_sq.data_ptr() if scored else None,
-                          self.score_cnt.data_ptr() if scored else None, n_layers, n_q_heads, n_kv_heads, head_dim, cap)
+                          self.score_cnt.data_ptr() if scored else None, n_layers, n_q_heads, n_kv_heads, head_dim, cap,
+                          self.arrive.data_ptr())
         self.rope_cos = self.rope_sin = None
         self.reset()
 

@@ -26,6 +26,7 @@
  *   score_sum     fp32  [n_layers][n_kv_heads][cap]             S  (sum p),      index j <-> position score_off + j
  *   score_sq      fp32  [n_layers][n_kv_heads][cap]             Q  (sum p^2)     (roco only)
  *   score_cnt     fp32  [n_layers][n_kv_heads][cap]             C  (#queries)    (roco only)
+ *   arrive        u32   [n_layers][n_kv_heads]                  optional arrival counters (see ekv_bank)
  *
  * Eviction never moves K/V rows: the victim's row is recycled for the next token and only the
  * 4-byte slot map is compacted (order-preserving, exactly the reference's list semantics).
@@ -67,6 +68,9 @@ typedef struct ekv_bank {
   int32_t *slot_of_pos;
   float *score_sum, *score_sq, *score_cnt;
   int32_t n_layers, n_q_heads, n_kv_heads, head_dim, cap;
+  uint32_t *arrive; /* optional (ABI 3), uint32 [n_layers][n_kv_heads], zeroed by ekv_bank_reset and left zero by every call:
+                       arrival counters of the split decode path.  With it the key-range partials of a head are folded inside the
+                       attention kernel by the last split to arrive (no fold launch); NULL = separate fold kernel.            */
 } ekv_bank;
 
 /* One model forward over `layer_count` layers starting at `layer_begin` (all layers share the

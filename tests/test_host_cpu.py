@@ -49,7 +49,7 @@ def test_abi_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from easykv_amd._lib import Bank, Step
-    assert ctypes.sizeof(Bank) == 6 * 8 + 5 * 4 + 4      # 6 pointers, 5 int32, tail padding
+    assert ctypes.sizeof(Bank) == 6 * 8 + 5 * 4 + 4 + 8      # 6 pointers, 5 int32, padding, the optional arrive pointer
     assert ctypes.sizeof(Step) == 18 * 4 + 5 * 4 + 2 * 4
     header = open(os.path.join(ROOT, "include", "easykv_hip.h")).read()
     body = header[header.index("typedef struct ekv_step {"):header.index("} ekv_step;")]
