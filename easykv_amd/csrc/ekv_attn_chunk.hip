@@ -8,17 +8,18 @@ EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 #undef EKV_DECL
 
 // Two-pass scheme (statistics pass + exact pass with in-kernel column sums, see ekv_attn_chunk.inc) for scored chunk
-// steps.  It trades one extra read of K for the rep x n x T logits never touching HBM.  Measured on MI355X,
-// once the one-pass kernel and the scorer's logits sweep were cleaned up the one-pass path wins at every BASELINE shape
-// (C4: 1.89 vs 2.31 ms per step, stride 64: 0.62 vs 0.67, C5 with RoPE-on-read: 1.98 vs 2.59), so `auto` never picks two
-// passes; ekv_step.two_pass = 1 selects them explicitly (kept tested: every golden case runs under both schemes) — the scheme
-// becomes the better one again if the statistics pass is made bandwidth-bound.  tova needs the last query row itself, not
-// column sums, and always uses the one-pass kernel.
-bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, int width, int mode) {
-  (void)width;
+// steps.  It trades one extra read of K (and a third MFMA product) for the rep x n x T logits never touching HBM: at rep*n = 96
+// the logits are 384 B per key against 512 B of K + V, written once and read once.  Measured on MI355X: in
+// round 1 the one-pass path won at every BASELINE shape (C4 1.89 vs 2.31 ms); with the round-2 instruction diet of the MFMA
+// kernel the two passes win from 64 query rows up (C4: 1.33 vs 1.48 ms per step, stride 64: 0.475 vs 0.50), so `auto` picks
+// them there.  Not with rope-on-read (every product is three MFMAs on the hi/lo pairs: C5 1.98 vs 2.59 ms).
+// ekv_step.two_pass = 1 / -1 selects a scheme explicitly (every golden case runs under both).  tova needs the last query row
+// itself, not column sums, and always uses the one-pass kernel.
+bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode) {
   const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // rep query heads share a 16-lane row
   const bool can = q_len > 1 && scored && accumulate && policy != EKV_POLICY_TOVA && rep_ok;
-  return can && mode > 0;
+  if (!can || mode < 0) return false;
+  return mode > 0 || (!rope && rep * q_len >= 64);
 }
 
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len) {

@@ -79,7 +79,7 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
                                  const EkvScoreArgs* fuse_sc = nullptr);
 size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs& a);
-bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, int width, int mode);
+bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode);
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 bool ekv_attn_decode_supported(int head_dim, int rep);

@@ -330,8 +330,8 @@ def test_one_launch_chunk_step_equals_two_launches_and_the_oracle(seed):
             o1, i1 = banks["one"].attend(StepPlan(n_split=1, two_pass=-1, **kw), q.cuda(), k.cuda(), v.cuda())
             o2 = torch.empty_like(o1)
             i2 = torch.empty_like(i1) if i1 is not None else None
-            banks["two"].attend(StepPlan(n_split=1, **kw), q.cuda(), k.cuda(), v.cuda(), out=o2, evict_ids=i2, phases=1)
-            banks["two"].attend(StepPlan(n_split=1, **kw), q.cuda(), k.cuda(), v.cuda(), out=o2, evict_ids=i2, phases=2)
+            banks["two"].attend(StepPlan(n_split=1, two_pass=-1, **kw), q.cuda(), k.cuda(), v.cuda(), out=o2, evict_ids=i2, phases=1)
+            banks["two"].attend(StepPlan(n_split=1, two_pass=-1, **kw), q.cuda(), k.cuda(), v.cuda(), out=o2, evict_ids=i2, phases=2)
             assert torch.equal(o1, o2), (seed, step)
             if i1 is not None:
                 assert torch.equal(i1, i2), (seed, step)
