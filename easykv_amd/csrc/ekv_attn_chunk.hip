@@ -30,7 +30,7 @@ bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len) {
 // workgroup (<= 32 / <= 64 rows); qpw = 4 selects the 8-wave workgroup (2 tiles per wave x 4 query-tile waves, <= 128 rows).
 void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw) {
   int rows = q_len;
-  if (rep * q_len > 128) rows = 128 / rep > 0 ? 128 / rep : 1;
+  if (rep * q_len > 128) rows = 128 / rep > 0 ? 128 / rep : 1;   // (64-row blocks on 4-wave workgroups: 324 vs 378 TFLOP/s on the dense prefix)
   // (65..128 rows stay ONE block on the 8-wave workgroup: two 4-wave blocks of <= 64 rows, even XCD-local so that the second K/V
   // read is an L2 hit, measured 1.55 vs 1.19 ms per C4 step)
   *qb_rows = rows;
