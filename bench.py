@@ -18,7 +18,7 @@ the next rank by an RCCL point-to-point pair per step, and a stage launches step
 has arrived (`--handoff overlap` posts it behind the next launch instead).  `--scaling weak` (also reported as a second
 key at N > 1): every rank owns a whole 32-layer block.  The rank-0 line carries `roofline` (dominant kernel, HIP events),
 `cpu_baseline` (the oracle timed on the host cores of the same box, bounded sample), `strided_prefill` (configs[1] and the
-wider strides of Bench-P) and `boundary_kernels` (gather / scatter / in-place compaction bandwidth).
+wider strides of Bench-P), `dense_prefix` (the unscored causal prefix, MFMA-bound) and `boundary_kernels` (gather / scatter / in-place compaction bandwidth).
 """
 from __future__ import annotations
 
@@ -237,6 +237,39 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
             "chunk_steps_timed": n_chunks, "slot_map": "identity" if args.identity_layout else "scattered"}
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (the 2:1-sparsity figure is never used)
+
+
+def dense_prefix(args, dev, S, stride, reps=3):
+    """Secondary figure: the dense causal prefix of a strided prefill (reference easykv.py:396, :403-405 with keep_attention off:
+    one forward over the first r_idx prompt tokens, no scoring).  All layers in one launch of the MFMA chunk kernel; flops =
+    4 * Hq * D * r_idx^2 / 2 per layer (causal half of QK^T and PV)."""
+    from easykv_amd import KVBank, StepPlan, geometry
+    L, Hq, D = args.layers, args.heads, args.head_dim
+    H = args.kv_heads or Hq
+    _, _, n = geometry("encoding", S, 0.5, stride)
+    g = torch.Generator(device=dev).manual_seed(99)
+    q, k, v = (torch.randn(L, h, n, D, generator=g, device=dev).half() for h in (Hq, H, H))
+    out = torch.empty(L, Hq, n, D, dtype=torch.float16, device=dev)
+    plan = StepPlan(policy="full", phase="prefill", accumulate=False)
+    ms = []
+    for _ in range(reps + 1):
+        bank = KVBank(L, Hq, H, D, cap=n + 8, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        bank.attend(plan, q, k, v, out=out)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        ms.append(ev[0].elapsed_time(ev[1]))
+        del bank
+    t = sum(ms[1:]) / reps * 1e-3          # (first run: kernel load)
+    fl = 4.0 * Hq * D * n * n / 2 * L
+    return {"workload": f"dense causal prefix of S={S} stride={stride}: r_idx={n} tokens, L={L} Hq={Hq} H={H} D={D}, one launch",
+            "ms": t * 1e3, "value": n / t, "unit": "prompt tokens/s (prefix, attention path only)",
+            "roofline": {"bound": "mfma", "achieved": fl / t / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / t / 1e12 / MFMA_F16_PEAK_TFLOPS, "flops": fl, "traffic": None}}
+
+
 def prefill_pmc(S, stride, L, Hq, H, D, policy):
     """HBM bytes per whole chunk step from the newest rocprofv3 PMC summary under profiles/ (tools/prof_round.sh +
     tools/summarize_prof.py: FETCH_SIZE / WRITE_SIZE in separate passes, 2 x FETCH + WRITE): the kernels one step launches."""
@@ -256,8 +289,12 @@ def prefill_pmc(S, stride, L, Hq, H, D, policy):
         if one:       # the whole step is one launch
             return one[0]["hbm_bytes_per_launch"], f"profiles/{os.path.basename(f)} [{stem}]: one launch per step"
         two = [v for n, v in ks.items() if "ekv_attn_chunk_kernel" in n or "ekv_score_select_kernel" in n]
-        if two:
-            return sum(v["hbm_bytes_per_launch"] for v in two), f"profiles/{os.path.basename(f)} [{stem}]: attention kernel + scorer kernel"
+        steps = [v["launches"] for n, v in ks.items() if "ekv_score_select_kernel" in n]
+        if two and steps:
+            # launches per step from the launch counts: the statistics pass and the exact pass of the two-pass scheme carry the same
+            # kernel name (one template, two translation units), so that entry is the mean of the two and counts twice per step
+            return (sum(v["hbm_bytes_per_launch"] * v["launches"] / steps[0] for v in two),
+                    f"profiles/{os.path.basename(f)} [{stem}]: attention kernel launch(es) + scorer kernel of one step")
     return None, None
 
 
@@ -627,6 +664,7 @@ def main():
             line["strided_prefill_more"] = [strided_prefill(args, dev, S=4096, stride=64, n_chunks=24),
                                             strided_prefill(args, dev, S=4096, stride=96, n_chunks=16),
                                             strided_prefill(args, dev, S=9994, stride=96, n_chunks=16)]
+            line["dense_prefix"] = [dense_prefix(args, dev, 4096, 8), dense_prefix(args, dev, 9994, 96)]
         if world == 1 and not args.no_boundary and not args.graph:
             line["boundary_kernels"] = boundary_kernels(args, dev)
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only

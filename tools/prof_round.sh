@@ -25,6 +25,7 @@ for cfg in "c2 4096 8 24" "s64 4096 64 12" "c4 9994 96 8"; do
   run_pmc chunk_$1_fetch FETCH_SIZE python $R/tools/bench_chunk.py $2 $3 $4
   run_pmc chunk_$1_write WRITE_SIZE python $R/tools/bench_chunk.py $2 $3 $4
 done
+bash $R/tools/sq_counters.sh > $OUT/sq_counters.txt 2>&1
 cd $R
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 ls $OUT

@@ -87,6 +87,11 @@ def main(src, tag):
                         ab = v
                 pre[stem]["note"] = "algorithmic bytes per step = algorithmic_bytes_per_step of bench.py (SURVEY.md §8d W_step x 32 layers)"
     json.dump(pre, open(f"profiles/{tag}_prefill_summary.json", "w"), indent=1)
+    sq = os.path.join(src, "sq_counters.txt")
+    if os.path.exists(sq) and os.path.getsize(sq):
+        with open(f"profiles/{tag}_sq_counters.txt", "w") as fo:
+            fo.write("# rocprofv3 --pmc (counters only, two passes) over tools/bench_prefix.py and tools/bench_chunk.py: tools/sq_counters.sh\n")
+            fo.write(open(sq).read())
     for name, d in (("decode", dec["pmc"]), ("prefill", {k: {kk: vv["hbm_bytes_per_launch"] for kk, vv in v["kernels"].items()} for k, v in pre.items()})):
         print(name, json.dumps(d, indent=1)[:1800])
 
