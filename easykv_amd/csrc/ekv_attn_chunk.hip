@@ -11,7 +11,7 @@ EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 // steps.  It trades one extra read of K (and a third MFMA product) for the rep x n x T logits never touching HBM: at rep*n = 96
 // the logits are 384 B per key against 512 B of K + V, written once and read once.  Measured on MI355X: in
 // round 1 the one-pass path won at every BASELINE shape (C4 1.89 vs 2.31 ms); with the round-2 instruction diet of the MFMA
-// kernel the two passes win from 64 query rows up (C4: 1.33 vs 1.48 ms per step, stride 64: 0.475 vs 0.50), so `auto` picks
+// kernel the two passes win from ~40 query rows up (C4: 1.17 vs 1.48 ms per step, stride 64: 0.43 vs 0.49), so `auto` picks
 // them there.  Not with rope-on-read (every product is three MFMAs on the hi/lo pairs: C5 1.98 vs 2.59 ms).
 // ekv_step.two_pass = 1 / -1 selects a scheme explicitly (every golden case runs under both).  tova needs the last query row
 // itself, not column sums, and always uses the one-pass kernel.
@@ -19,7 +19,7 @@ bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumu
   const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // rep query heads share a 16-lane row
   const bool can = q_len > 1 && scored && accumulate && policy != EKV_POLICY_TOVA && rep_ok;
   if (!can || mode < 0) return false;
-  return mode > 0 || (!rope && rep * q_len >= 64);
+  return mode > 0 || (!rope && rep * q_len >= 40);   // measured crossover: 32 rows 0.34 (one pass) vs 0.36 ms, 48 rows 0.42 vs 0.41 ms
 }
 
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len) {

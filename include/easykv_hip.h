@@ -97,7 +97,7 @@ typedef struct ekv_step {
   float count_add;      /* added to C before selection (1 decode, stride prefill); 0 = leave             */
   float count_tail_step;/* C tail after compaction: tail[i] = i * count_tail_step (0 decode, -1 prefill) */
   float sm_div;         /* logits are divided by this (sqrt(head_dim))                                   */
-  int32_t two_pass;     /* scored chunk steps: 0 = library decides (two passes from 64 GQA-folded query rows, one pass below,
+  int32_t two_pass;     /* scored chunk steps: 0 = library decides (two passes from 40 GQA-folded query rows, one pass below,
                            for tova and with rope_on_read), 1 = statistics pass + exact pass with in-kernel column sums
                            whenever the shape allows it, -1 = always one pass with exported logits                      */
   int32_t phys_extent;  /* E: every live row of these layers has a physical index < E (n_slots <= E <= cap), and rows

@@ -13,7 +13,14 @@ pytestmark = pytest.mark.gpu
 
 
 class Probe:
+    """Stability probe of one selection: the oracle's own decision re-run on scores perturbed by +-2e-5 relative noise; a decision
+    that moves under any of the draws is not well defined at fp32 and is excluded from the comparison.  TRIALS: a near-tie (margin
+    far below the noise) escapes one draw with probability ~1/2, so three draws let 13 % of them through — and which way the
+    oracle itself resolves such a tie can depend on the host CPU's libm / BLAS code path.  (One long-run test failed once in
+    ~15 runs on the GPU pool and never again on other boxes or with poisoned device memory; an undetected near-tie is the one
+    explanation that fits.)  Six draws let 1.6 % through."""
     PERT = 2e-5
+    TRIALS = 6
 
     def __init__(self):
         self.gen = torch.Generator().manual_seed(7)
@@ -22,7 +29,7 @@ class Probe:
     def __call__(self, fn, policy, s, q, c, args, ids):
         base = torch.sort(ids, dim=-1)[0]
         bad = torch.zeros(ids.shape[:-1], dtype=torch.bool)
-        for _ in range(3):
+        for _ in range(self.TRIALS):
             e1 = 1.0 + (torch.rand(s.shape, generator=self.gen) * 2 - 1) * self.PERT
             e2 = 1.0 + (torch.rand(s.shape, generator=self.gen) * 2 - 1) * self.PERT
             alt = fn(policy, s * e1, q * e2, c.clone(), *args)
