@@ -183,6 +183,12 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
     const int target = (st->q_len > 1 && qpw == 1) ? 3072 : 1024;
     n_split = std::max(1, std::min((target + wgs - 1) / wgs, st->q_len == 1 ? (T + 127) / 128 : (T + 255) / 256));
   }
+  if (st->q_len > 1) {
+    // the chunk kernel caches the slot indices of its key range in LDS next to its tiles and query block: bound the range
+    // (an unsplit 32 k-slot head would need 128 KB of indices alone; split heads fold through the partials instead)
+    const int max_rows = st->rope_on_read ? 6144 : 16384;
+    n_split = std::max(n_split, (T + max_rows - 1) / max_rows);
+  }
   int rows = (int)ekv_align((size_t)(T + n_split - 1) / n_split, wg_unit);
   w.rows_per_split = rows;
   w.n_split = (T + rows - 1) / rows;
@@ -207,6 +213,11 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   off += ekv_align(rowsq * w.n_partials * (bank->head_dim + 2) * 4, 256);
   w.tova_row = reinterpret_cast<float*>(p + off);
   off += ekv_align((size_t)st->layer_count * w.t_pad * 4, 256);
+  w.big_rows = nullptr;
+  if (scored && ekv_score_rows_exceed_lds(T - st->score_off, rep * st->q_len)) {   // W > ~10 000: rows in scratch, keys in LDS
+    w.big_rows = reinterpret_cast<float*>(p + off);
+    off += ekv_align((size_t)st->layer_count * bank->n_kv_heads * 3 * w.t_pad * 4, 256);
+  }
   // unsplit chunk steps fold the two key halves inside the attention kernel (one-pass scored steps also get the final row
   // statistics from it)
   w.fold_in_kernel = (st->q_len > 1 && w.n_split == 1) ? 1 : 0;
@@ -324,6 +335,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
     if (ws.logits) ws.logits += rows0 * ws.t_pad;
     ws.partials += rows0 * ws.n_partials * (bank->head_dim + 2);
     ws.tova_row += (size_t)st->defer_index * ws.t_pad;
+    if (ws.big_rows) ws.big_rows += (size_t)st->defer_index * bank->n_kv_heads * 3 * ws.t_pad;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -399,6 +411,9 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   sa.count_add = st->count_add;
   sa.count_tail_step = st->count_tail_step;
 
+  sa.big_rows = ws.big_rows;
+  sa.big_stride = ws.t_pad;
+
   drop_stale_error();
   // whole decode step in one launch when no head has to be split
   if (n == 1 && st->phases == 0 && ws.n_split == 1 &&
@@ -433,7 +448,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   const bool range_only = wants_scorer && st->policy == EKV_POLICY_RANGE;
   const bool fast_scorer = wants_scorer && !fold_only && !range_only && !fuse_chunk && ekv_decode_score_supported(sa);
   if (wants_scorer && !fold_only && !range_only && !fuse_chunk && !fast_scorer && ekv_score_lds_bytes(sa) > 160 * 1024)
-    return EKV_E_UNSUPPORTED;   // scored rows wider than one CU's LDS (W > ~10 000): see DESIGN.md "size limits"
+    return EKV_E_UNSUPPORTED;   // even the selection keys alone exceed one CU's LDS (W > ~39 000): see DESIGN.md "size limits"
   if (n == 1 ? !ekv_attn_decode_supported(bank->head_dim, rep) : !ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
 
   // decode split path whose partials are folded right behind the attention kernel (attention + fold phases, or a step that has

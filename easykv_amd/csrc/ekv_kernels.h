@@ -11,6 +11,7 @@ struct EkvWs {
   float* logits;    // [layer_count][Hq][q_len][t_pad]   raw q.k/sm_div of every live position
   float* partials;  // [layer_count][Hq][q_len][n_split][D+2]   (m, l, o[D]) per key-range split
   float* tova_row;  // [layer_count][t_pad]   head-averaged last-query row (tova_head_mean)
+  float* big_rows;  // [layer_count][H][3][t_pad] working copies of the score rows when they exceed one CU's LDS, else null
   float* stats;     // two-pass chunk steps (see EkvAttnArgs)
   float* colsum;
   int32_t two_pass, n_col_parts;
@@ -61,6 +62,8 @@ struct EkvScoreArgs {
   const float* logits;
   const float* partials;
   const float* colsum;   // non-null: column sums from the two-pass chunk kernel replace the logits
+  float* big_rows;       // non-null: score rows wider than one CU's LDS — the scorer keeps its working copies of S / Q / C in this
+  int big_stride;        //   scratch ([layer_count][H][3][big_stride] floats) and only the selection keys in LDS
   const float* row_stats;   // non-null: final row statistics written by the chunk kernel (its in-kernel fold)
   int32_t n_col_parts;
   float* tova_row;
@@ -79,6 +82,7 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
                                  const EkvScoreArgs* fuse_sc = nullptr);
 size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs& a);
+bool ekv_score_rows_exceed_lds(int W, int rows);   // generic scorer: S / Q / C + keys of W columns do not fit 160 KB of LDS
 bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode);
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);

@@ -11,11 +11,17 @@ hipError_t ekv_launch_tova_headmean_nt512(const EkvScoreArgs&, int, hipStream_t)
 size_t ekv_score_lds_bytes_nt1024(const EkvScoreArgs&);
 hipError_t ekv_launch_score_select_nt1024(const EkvScoreArgs&, int, hipStream_t);
 
-size_t ekv_score_lds_bytes(const EkvScoreArgs& a) { return ekv_score_lds_bytes_nt512(a); }
+size_t ekv_score_lds_bytes(const EkvScoreArgs& a) { return a.big_rows != nullptr ? ekv_score_lds_bytes_nt1024(a) : ekv_score_lds_bytes_nt512(a); }
+
+// (mirrors ekv_score_lds_bytes_nt512 with all four arrays in LDS; decided at workspace-planning time, before the arguments exist)
+bool ekv_score_rows_exceed_lds(int W, int rows) {
+  return ekv_align((size_t)(4 * (size_t)W + 2 * (size_t)rows) * 4, 16) + 2 * 8 * 8 * 4 + 264 * 4 + 512 * 8 > 160 * 1024;
+}
 
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s) {
   // 256 threads only while at least three such workgroups fit a CU's LDS; wide score rows (C4: W = 5098 -> 82 KB) leave
   // room for one workgroup per CU, which must then bring 512 threads
+  if (a.big_rows != nullptr) return ekv_launch_score_select_nt1024(a, layer_count, s);   // rows in global scratch, keys in LDS
   const bool small_blocks = a.n_kv_heads * layer_count >= 768 && ekv_score_lds_bytes_nt256(a) <= 53 * 1024;
   if (small_blocks) return ekv_launch_score_select_nt256(a, layer_count, s);
   // one workgroup per CU either way (at most one (head, layer) pair per CU, or LDS rows too wide for two): give it all 16

@@ -198,6 +198,62 @@ def test_c4_shape_stride96_and_long_decode_rows():
     _check_permutation(bank)
 
 
+@pytest.mark.parametrize("policy,idx,s", [("roco", 12400, 16), ("h2o_head", 12400, 16), ("roco", 16400, 48), ("roco", 30000, 8)])
+def test_wide_score_rows_beyond_one_cus_lds(policy, idx, s):
+    """A 16K-context cache at budget 0.75 (W = 12.4 k columns per head: the score rows + selection keys of one head are 198 KB,
+    more than a CU's 160 KB of LDS — VERDICT r1 "size limits").  The generic scorer then keeps its working copies of S / Q / C in
+    global scratch and only the keys in LDS; same arithmetic, so the usual bar holds: two scored chunk steps (stride 16, 16
+    victims per head) and three budgeted decode steps against the oracle, eviction sets identical wherever the probe calls the
+    decision well defined."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    H, D = 2, 64      # (idx 16400 / stride 48: a 32K context at budget 0.5 through the two-pass chunk kernels; 30000: near the limit)
+    bp, recent, sink = idx, int(idx * 0.1), 4
+    g = torch.Generator().manual_seed(31)
+    k0, v0 = torch.randn(1, H, idx, D, generator=g).half(), torch.randn(1, H, idx, D, generator=g).half()
+    bank = KVBank(1, H, H, D, cap=idx + s)
+    bank.load_rows(k0.cuda(), v0.cuda())
+    bank.state_init(idx + s, 2, s)
+    st = O.LayerState(k=k0.float(), v=v0.float())
+    st.s, st.q, st.c = O.init_state_prefill((H,), idx, s, False)
+    probe = Probe()
+    O.SELECT_HOOK = probe
+    checked = 0
+    try:
+        for step in range(2):
+            q, k, v = (torch.randn(1, H, s, D, generator=g).half() for _ in range(3))
+            kw = dict(policy=policy, phase="prefill", accumulate=True, evict=True, budget=bp, recent=recent, sink=sink, stride=s)
+            out, ids = bank.attend(StepPlan(**kw), q.cuda(), k.cuda(), v.cuda())
+            o_ref, ids_ref = O.layer_step(st, q.float(), k.float(), v.float(), O.StepPlan(**kw))
+            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4)
+            got, ref = torch.sort(ids[0].cpu().long(), dim=-1)[0], torch.sort(ids_ref, dim=-1)[0]
+            ok = ~probe.last_unstable
+            assert bool((got == ref).all(dim=-1)[ok].all()), step
+            checked += int(ok.sum())
+            if not bool(ok.all()):
+                pytest.skip("near-tie in this draw")
+        for name, row in (("score_sum", st.s), ("score_sq", st.q)):
+            if policy == "roco" or name == "score_sum":
+                assert torch.allclose(getattr(bank, name)[0, :, :idx].cpu(), row[..., :idx], rtol=2e-4, atol=1e-6), name
+        st.s, st.q, st.c = (x[..., :-(s - 1)].clone() for x in (st.s, st.q, st.c))   # easykv/easykv.py:666-669
+        for step in range(3):
+            q, k, v = (torch.randn(1, H, 1, D, generator=g).half() for _ in range(3))
+            kw = dict(policy=policy, phase="decode", accumulate=True, evict=True, budget=bp)
+            out, ids = bank.attend(StepPlan(**kw), q.cuda(), k.cuda(), v.cuda())
+            o_ref, ids_ref = O.layer_step(st, q.float(), k.float(), v.float(), O.StepPlan(**kw))
+            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=5e-4)
+            ok = ~probe.last_unstable
+            assert bool((ids[0, :, 0].cpu().long() == ids_ref[:, 0])[ok].all()), step
+            checked += int(ok.sum())
+            if not bool(ok.all()):
+                pytest.skip("near-tie in this draw")
+    finally:
+        O.SELECT_HOOK = None
+    assert checked == 5 * H
+    assert bank.n_slots[0] == idx
+    _check_permutation(bank)
+
+
 def test_baseline_config0_geometry_decoding_budget200():
     """BASELINE.json configs[0]: decoding mode, budget=200, kv_policy='roco' (test_decoding.py:29-48 uses 300 / 150):
     W = 201, recent = int(200*0.3) = 60, k1 = 140; Llama2-7B head shape, prompt of 37 tokens that is never evicted."""
