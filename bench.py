@@ -545,6 +545,44 @@ def latest_pmc_summary(L, Hq, H, D, budget, policy, lpl):
     return None, None
 
 
+def live_pmc(extra_args, kernel_substr, timeout_s=150, script=None):
+    """HBM traffic of the dominant kernel measured in THIS run: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate
+    passes (counters only — never together with a trace), each over a short child run of this same bench command (16 timed steps),
+    corrected as MI355X_MICROARCH.md prescribes for gfx950 (2 x FETCH_SIZE + WRITE_SIZE, KiB).  -> (bytes per launch, source) or
+    (None, reason).  Same recipe as tools/prof_round.sh, which also keeps the raw files under profiles/."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ekv_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable]
+        cmd += ([script] if script else [os.path.abspath(__file__), "--no-cpu-baseline", "--steps", "16", "--warmup", "4", "--prewarm-s", "0.05",
+                                         "--no-prefill", "--no-boundary", "--no-live-pmc"]) + extra_args
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout_s, check=False)
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[0]))
+                 if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == ctr] if fs else []
+        except Exception as e:      # a profiler hiccup must never cost the bench line
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"live PMC pass failed ({type(e).__name__})"
+        shutil.rmtree(d, ignore_errors=True)
+        if len(v) < 4:
+            return None, f"live PMC pass saw {len(v)} launches of the kernel"
+        v = v[2:]
+        vals[ctr] = sum(v) / len(v)
+    return ((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over 16 timed steps of this command, "
+            "2 x FETCH + WRITE (gfx950 correction, KiB -> bytes)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -567,6 +605,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--step-events", action="store_true", help="fused path: bracket every launch with its own HIP event pair instead "
                     "of one pair around the timed region (adds ~6 us of marker latency per step)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from profiles/ instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--no-prefill", action="store_true", help="skip the secondary strided-prefill (configs[1]) figures")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-kernel bandwidth figures")
     ap.add_argument("--no-handoff", action="store_true")
@@ -632,6 +671,14 @@ def main():
                                           "latency-bound; not the headline value"}
         if fused:
             traffic, traffic_src = latest_pmc_summary(args.layers, Hq, H, D, budget, args.policy, lpl) if world == 1 else (None, None)
+            if world == 1 and not args.no_live_pmc:
+                passthrough = ["--layers", str(args.layers), "--heads", str(args.heads), "--kv-heads", str(args.kv_heads),
+                               "--head-dim", str(args.head_dim), "--budget", str(args.budget), "--policy", args.policy]
+                live, live_src = live_pmc(passthrough, "ekv_decode_fused_kernel")
+                if live is not None:
+                    traffic, traffic_src = live, live_src
+                elif traffic is not None:
+                    traffic_src += f" (live collection unavailable: {live_src})"
             gbs = b["total"] * lc0 / t_attn / 1e9
             line["roofline"] = {"bound": "hbm", "kernel": "ekv_decode_fused_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -661,6 +708,13 @@ def main():
                                      "score_select_us": t_score * 1e6}
         if world == 1 and not args.no_prefill and not args.graph:
             line["strided_prefill"] = strided_prefill(args, dev)
+            sp = line["strided_prefill"]
+            if not args.no_live_pmc and sp.get("one_launch") and (args.layers, Hq, H, D, args.policy) == (32, 32, 32, 128, "roco"):
+                # configs[1]: the whole chunk step is one launch of the logits-in-LDS kernel — its traffic measured in this run
+                live, live_src = live_pmc(["4096", "8", "16"], "ekv_chunk_lds_kernel", script=os.path.join(ROOT, "tools", "bench_chunk.py"))
+                if live is not None:
+                    sp["roofline"].update(traffic=live, traffic_source=live_src.replace("of this command", "of tools/bench_chunk.py 4096 8"),
+                                          traffic_over_algorithmic=live / sp["roofline"]["bytes_per_step"])
             line["strided_prefill_more"] = [strided_prefill(args, dev, S=4096, stride=64, n_chunks=24),
                                             strided_prefill(args, dev, S=4096, stride=96, n_chunks=16),
                                             strided_prefill(args, dev, S=9994, stride=96, n_chunks=16)]

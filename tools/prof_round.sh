@@ -15,9 +15,9 @@ run_pmc() {   # name, counter, command...
   mkdir -p $OUT/$name
   cp $(find /tmp/p_$name -name "*counter_collection.csv" | head -1) $OUT/$name/ 2>/dev/null
 }
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- python $R/bench.py --steps 512 --no-cpu-baseline > $OUT/bench_under_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trace -- python $R/bench.py --steps 512 --no-cpu-baseline --no-live-pmc > $OUT/bench_under_trace.log 2>&1
 mkdir -p $OUT/trace; cp $(find /tmp/p_trace -name "*kernel_stats.csv" | head -1) $OUT/trace/
-D="python $R/bench.py --no-cpu-baseline --steps 16 --warmup 4 --prewarm-s 0.05 --no-prefill --no-boundary"
+D="python $R/bench.py --no-cpu-baseline --no-live-pmc --steps 16 --warmup 4 --prewarm-s 0.05 --no-prefill --no-boundary"
 run_pmc decode_fetch FETCH_SIZE $D
 run_pmc decode_write WRITE_SIZE $D
 for cfg in "c2 4096 8 24" "s64 4096 64 12" "c4 9994 96 8"; do
