@@ -199,7 +199,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   w.logits = nullptr;
   w.stats = w.colsum = nullptr;
   w.two_pass = ekv_chunk_two_pass(rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass) ? 1 : 0;
-  w.n_col_parts = (qpw == 4 ? 4 : 2) * w.n_qblocks;   // query-tile waves per workgroup x query blocks
+  w.n_col_parts = ekv_chunk_col_parts(qpw, st->rope_on_read != 0) * w.n_qblocks;   // query-tile waves per workgroup x query blocks
   if (w.two_pass) {   // statistics partials + column sums instead of the logits
     w.stats = reinterpret_cast<float*>(p + off);
     off += ekv_align(rowsq * w.n_partials * 2 * 4, 256);

@@ -56,6 +56,16 @@ __global__ void __launch_bounds__(128) ekv_rope_q_kernel(const EkvAttnArgs a, in
   }
 }
 
+// 65..128-row blocks (qpw code 4): 8 waves x 2 query tiles — except the ONE-PASS kernel without rope-on-read, which runs SIXTEEN
+// waves x 1 query tile (kernel code 8): <= 128 VGPRs per wave, so four waves per SIMD instead of two; the tile loop is a chain of
+// LDS / MFMA / VALU latencies between two barriers and two waves per SIMD do not hide it (dense prefix 4906 tokens 411 -> 445
+// TFLOP/s, 2048 tokens 319 -> 392).  The exact pass of the two-pass scheme stays on 8 waves: with 16 it writes twice the
+// column-sum partial rows, which costs the scorer more than the attention kernel gains (C4 step 1.16 -> 1.25 ms, measured).
+static int kernel_code(int qpw, bool rope, int mode) { return (qpw == 4 && !rope && mode == 0) ? 8 : qpw; }
+
+// partial column-sum rows the exact pass writes per (head, query block) = its query-tile waves
+int ekv_chunk_col_parts(int qpw, bool rope) { (void)rope; return qpw == 4 ? 4 : 2; }
+
 // fuse_sc != nullptr: one-pass step with unsplit heads whose scorer runs as the tail of the attention kernel (no second launch)
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
                                  const EkvScoreArgs* fuse_sc) {
@@ -67,8 +77,9 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
   if (qb_rows != a.qb_rows || n_qblocks != a.n_qblocks) return hipErrorInvalidValue;
-  if (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts != (qpw == 4 ? 4 : 2) * n_qblocks)) return hipErrorInvalidValue;
-#define EKV_GO(d, m) ekv_launch_attn_chunk_d##d##_m##m(a, qpw, layer_count, s, fuse_sc)
+  const bool rope = a.rope_cos != nullptr;
+  if (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts != ekv_chunk_col_parts(qpw, rope) * n_qblocks)) return hipErrorInvalidValue;
+#define EKV_GO(d, m) ekv_launch_attn_chunk_d##d##_m##m(a, kernel_code(qpw, rope, m), layer_count, s, fuse_sc)
   hipError_t e = hipSuccess;
   switch (head_dim) {
     case 32: e = two_pass ? EKV_GO(32, 1) : EKV_GO(32, 0); if (two_pass && e == hipSuccess) e = EKV_GO(32, 2); break;

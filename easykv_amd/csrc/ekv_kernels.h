@@ -93,6 +93,7 @@ int ekv_fused_logit_pad(const ekv_bank* bank, const ekv_step* st, int t_pad);
 hipError_t ekv_launch_decode_fused(const EkvAttnArgs& a, const EkvScoreArgs& sc, int head_dim, int layer_count, int nw, hipStream_t s);
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len);
 void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw);
+int ekv_chunk_col_parts(int qpw, bool rope);
 size_t ekv_score_lds_bytes(const EkvScoreArgs& a);
 bool ekv_decode_score_supported(const EkvScoreArgs& sc);
 hipError_t ekv_launch_decode_score(const EkvScoreArgs& sc, int layer_count, hipStream_t s);
