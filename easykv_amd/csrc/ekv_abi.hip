@@ -182,6 +182,10 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
     // exactly 1024 would leave a quarter of it to a second, nearly empty round, so QPW=1 aims at 4 full rounds (3072).
     const int target = (st->q_len > 1 && qpw == 1) ? 3072 : 1024;
     n_split = std::max(1, std::min((target + wgs - 1) / wgs, st->q_len == 1 ? (T + 127) / 128 : (T + 255) / 256));
+    // decode launches of a few heads (one layer per call): the launch is latency-bound and ends with the fold of the key-range
+    // partials, whose loads go out in batches of 8 — up to 8 splits are ONE round trip.  Measured at 32 heads, T = 2049
+    // (us per layer, attention + in-kernel fold): 5 splits 15.4, 6..8 13.7, 10..17 14.6..14.7.
+    if (st->q_len == 1 && n_split > 8 && wgs * 8 >= 256) n_split = 8;
   }
   if (st->q_len > 1) {
     // the chunk kernel caches the slot indices of its key range in LDS next to its tiles and query block: bound the range
