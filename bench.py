@@ -205,7 +205,7 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
     ev[1].record()
     torch.cuda.synchronize(dev)
     t_step = ev[0].elapsed_time(ev[1]) / n_chunks * 1e-3
-    one_launch = bool(bank.step_plan(plan, stride)[0] == 1 and Hq // H * stride <= 64)
+    one_launch = bool(bank.step_plan(plan, stride)[1])     # what the library's own dispatch says (two passes = 3 launches)
     # ... and the same step as two launches (attention kernel, then fold + score + select + compaction), for the breakdown
     ev2 = []
     for i in range(warm + 8):

@@ -16,7 +16,7 @@ POLICY_CODES = {"full": POLICY_NONE, "h2o_head": POLICY_H2O_HEAD, "roco": POLICY
                 "recency": POLICY_RANGE, "random": POLICY_RANGE}
 
 EXPORTS = ("ekv_abi_version", "ekv_strerror", "ekv_workspace_bytes", "ekv_step_plan", "ekv_bank_reset", "ekv_state_init",
-           "ekv_step_attend", "ekv_gather_ordered", "ekv_scatter_rows", "ekv_compact_inplace")
+           "ekv_step_attend", "ekv_gather_ordered", "ekv_scatter_rows", "ekv_compact_inplace", "ekv_step_check")
 
 
 class Bank(C.Structure):
@@ -65,9 +65,10 @@ def load():
     lib.ekv_gather_ordered.argtypes = [C.POINTER(Bank), i32, i32, i32, vp, vp, vp]
     lib.ekv_scatter_rows.argtypes = [C.POINTER(Bank), i32, i32, i32, i32, vp, vp, vp]
     lib.ekv_compact_inplace.argtypes = [C.POINTER(Bank), i32, i32, i32, i32, vp, vp]
+    lib.ekv_step_check.argtypes = [C.POINTER(Bank), C.POINTER(Step)]
     for name in EXPORTS[3:]:
         getattr(lib, name).restype = C.c_int
-    if lib.ekv_abi_version() != 3:
+    if lib.ekv_abi_version() != 4:
         raise EkvError("ABI version mismatch")
     _lib = lib
     return lib

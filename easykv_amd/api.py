@@ -120,6 +120,7 @@ class BudgetedKVCache:
         return key_states, value_states
 
     def begin_forward(self, plan: StepPlan, positions=None):
+        self.bank.abort_step()     # a previous forward that raised between two layers leaves a half-open deferred token step
         self.plan = plan
         self.positions = positions
         self.n_attend = 0
@@ -241,7 +242,27 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
     shard = getattr(self, "layer_shard", None)
     if shard is not None and shard.world == 1:
         shard = None
+    if shard is not None:
+        if shard.world > n_layers or shard.count < 1:
+            raise ValueError(f"layer sharding over {shard.world} ranks needs at least one of the model's {n_layers} layers per rank")
+        if use_graph:
+            # a captured forward would contain the stage hand-off (dist.send / dist.recv and, on gloo, host staging)
+            raise ValueError("generation_config['hipgraph'] is not supported on a layer-sharded model (model.layer_shard)")
     l_begin, l_count = (shard.begin, shard.count) if shard is not None else (0, n_layers)
+
+    def policy_draw(n, mask_tail=0):
+        """kv_policy='random': the reference's own draw — argmax of torch.rand on the global CPU generator over the row
+        (easykv/easykv.py:354-356; the chunk's own columns excluded in prefill, :494-497).  Layer-sharded: every rank draws
+        (generators seeded alike stay in step) and rank 0's value is the one all ranks evict, as the reference evicts one
+        range in all layers."""
+        draw = torch.rand(n)
+        if mask_tail:
+            draw[-mask_tail:] = -1e9
+        e = int(torch.topk(draw, k=1, dim=-1)[1][0])
+        if shard is not None:
+            from . import dist as DS
+            e = int(DS.broadcast_object(e, 0))
+        return e
 
     if kv_mode == "auto":                                      # easykv/easykv.py:220-227
         assert type(budget) == int
@@ -300,24 +321,29 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
             tok = torch.zeros(1, 1, dtype=torch.long, device=dev)
         return DS.broadcast(tok, last_rank)
 
-    eos_poll = max(1, int(cfg.get("eos_poll", 16)))   # extension key: host looks at the sampled tokens every N tokens
+    # extension key: the host looks at the sampled tokens every N tokens.  Default 1 = the reference's control flow (it tests
+    # every token before feeding it, easykv/easykv.py:257-263); N > 1 is opt-in, see TokenLog
+    eos_poll = max(1, int(cfg.get("eos_poll", 1)))
 
     class TokenLog:
         """Sampled tokens stay on the device.  The reference pulls every token to the host to test it for EOS
         (`.cpu()` / `.item()`, ~5 syncs per token, easykv/easykv.py:257-283); here the host polls the device-side log once per
-        ``eos_poll`` tokens: ONE host sync per ``eos_poll`` tokens.  ``eos_poll=1`` is the reference's exact control flow; with
-        N > 1 up to N-1 forwards run past an EOS before it is seen — wasted work only: the returned text and the printed
-        budget line are those of the reference (cut at the first EOS; counts derived from the EOS index, not from the cache)."""
+        ``eos_poll`` tokens: ONE host sync per ``eos_poll`` tokens.  ``eos_poll=1`` (the default) is the reference's exact
+        control flow: nothing runs past an EOS.  With N > 1 (opt-in) up to N-1 forwards run past an EOS before it is seen:
+        the returned text and the printed budget line are still the reference's (cut at the first EOS; counts derived from
+        the EOS index, not from the cache), but those forwards have evicted from the cache handed back by
+        ``return_cache=True`` and have drawn from the sampler's / the 'random' policy's generators."""
 
         def __init__(self):
             self.buf = torch.empty(max(1, max_new_tokens), dtype=torch.long, device=dev)
             self.eos = torch.as_tensor([int(e) for e in eos_token_ids], dtype=torch.long, device=dev)
-            self.n = self.checked = self.syncs = 0
+            self.n = self.checked = self.syncs = self.sampled = 0
             self.stopped_by_eos = False
 
         def push(self, tok):
             self.buf[self.n:self.n + 1].copy_(tok.view(1))
             self.n += 1
+            self.sampled += 1      # every token drawn, including those past an EOS a later poll cuts off
 
         def poll(self):
             """True when the loop must stop: an EOS was found among the tokens not looked at yet (``n`` is cut back to it)."""
@@ -391,7 +417,7 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                 else:                                           # :343-362: oldest / uniformly random generated slot
                     # 'random': the reference's own draw — argmax of torch.rand over the generated slots, CPU generator
                     # (easykv/easykv.py:354-356), so a run seeded like a reference run evicts the same slots
-                    e = 0 if policy == "recency" else int(torch.topk(torch.rand(len(positions)), k=1, dim=-1)[1][0])
+                    e = 0 if policy == "recency" else policy_draw(len(positions))
                     positions.pop(e)
                     plan.range_start = score_off + e
             # steady state (same plan, same cache length as the step before, one slot evicted per step): replay the graph
@@ -404,7 +430,7 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                 logits_last = forward(cache, tok.view(1, 1), [cur_pos], plan).logits[:, -1, :]
             prev_sig = sig
             cur_pos += 1
-        cache.host_syncs, cache.tokens_sampled = log.syncs, log.n
+        cache.host_syncs, cache.tokens_sampled = log.syncs, log.sampled
         return log.ids(), log.fed
 
     # ---- dense prefix + strided chunks with eviction (encoding, auto, ppl) ---------------------------------
@@ -428,9 +454,7 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
             if plan.evict and policy == "recency":
                 plan.range_start = sink                          # :491-493
             elif plan.evict and policy == "random":              # :494-499: argmax of torch.rand over the row, chunk excluded
-                draw = torch.rand(idx + stride)
-                draw[-stride:] = -1e9
-                plan.range_start = int(torch.topk(draw, k=1, dim=-1)[1][0])
+                plan.range_start = policy_draw(idx + stride, stride)
             out = forward(cache, input_ids[:, tok_i:tok_i + stride], list(range(cur_pos, cur_pos + stride)), plan)
             logits_last = out.logits[:, -1, :]
             if keep_logits:
@@ -478,7 +502,7 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                 t_first = time.time()
             cur_pos += 1
         out_ids = log.ids()
-        cache.host_syncs, cache.tokens_sampled = log.syncs, log.n
+        cache.host_syncs, cache.tokens_sampled = log.syncs, log.sampled
         result = self.tokenizer.decode(out_ids, skip_special_tokens=True).strip()
         if report_decoding_latency and n_fwd > 1:
             torch.cuda.synchronize(dev)

@@ -267,14 +267,19 @@ size_t ekv_workspace_bytes(const ekv_bank* bank, const ekv_step* step) {
   return ekv_plan_workspace(bank, &full, nullptr).bytes;
 }
 
+static int step_attend_impl(const ekv_bank*, const ekv_step*, const void*, const void*, const void*, void*, int32_t*, const float*,
+                            const float*, void*, size_t, void*, bool, int32_t*);
+
 int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, int32_t* fused) {
   if (int e = check_bank(bank)) return e;
   if (!st || !n_split || !fused) return EKV_E_ARG;
   const EkvWs ws = ekv_plan_workspace(bank, st, nullptr);
   *n_split = ws.n_split;
-  *fused = (st->q_len == 1 && st->phases == 0 && st->n_split != -1 && ws.n_split == 1 &&
-            ekv_decode_fused_supported(bank->head_dim, bank->n_q_heads / bank->n_kv_heads, st->n_slots, ws.t_pad, ekv_fused_logit_pad(bank, st, ws.t_pad), st->n_evict, bank->cap, ws.fused_nw))
-               ? 1 : 0;
+  // one launch for the whole step: the fused decode kernel, the logits-in-LDS chunk kernel, or a chunk step whose scorer runs
+  // as the tail of the attention kernel — asked of the dispatch itself (dry run); a step the dispatch would refuse plans as 0
+  int32_t one = 0;
+  if (step_attend_impl(bank, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true, &one) != EKV_OK) one = 0;
+  *fused = (one && st->phases == 0) ? 1 : 0;
   return EKV_OK;
 }
 
@@ -302,11 +307,18 @@ int ekv_state_init(const ekv_bank* bank, int32_t layer_begin, int32_t layer_coun
   return launch_status();
 }
 
-int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, const void* k_new, const void* v_new,
-                    void* out, int32_t* evict_ids, const float* rope_cos, const float* rope_sin, void* workspace,
-                    size_t workspace_bytes, void* stream) {
+}  // extern "C"
+
+// Body of ekv_step_attend.  `dry` (ekv_step_check): every argument / shape / capability test of the real call, in the same
+// order, and a return right before the first launch — nothing is launched, no pointer is dereferenced, the workspace is not
+// needed.
+static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void* q, const void* k_new, const void* v_new,
+                            void* out, int32_t* evict_ids, const float* rope_cos, const float* rope_sin, void* workspace,
+                            size_t workspace_bytes, void* stream, bool dry, int32_t* one_launch) {
+  if (one_launch) *one_launch = 0;
   if (int e = check_bank(bank)) return e;
-  if (!st || !q || !k_new || !v_new || !out || !workspace) return EKV_E_ARG;
+  if (!st) return EKV_E_ARG;
+  if (!dry && (!q || !k_new || !v_new || !out || !workspace)) return EKV_E_ARG;
   if (int e = check_layers(bank, st->layer_begin, st->layer_count)) return e;
   const int T = st->n_slots, n = st->q_len;
   if (n < 1 || T < n || T > bank->cap || st->n_evict < 0 || st->n_evict >= T) return EKV_E_ARG;
@@ -315,7 +327,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   if (scored && (!bank->score_sum || st->score_off < 0 || st->score_off >= T)) return EKV_E_ARG;
   if (st->policy == EKV_POLICY_ROCO && (!bank->score_sq || !bank->score_cnt)) return EKV_E_ARG;
   if (st->policy < EKV_POLICY_NONE || st->policy > EKV_POLICY_RANGE) return EKV_E_ARG;
-  if (st->rope_on_read && (!rope_cos || !rope_sin)) return EKV_E_ARG;
+  if (!dry && st->rope_on_read && (!rope_cos || !rope_sin)) return EKV_E_ARG;
   const int W = T - (scored ? st->score_off : 0);
   if (st->n_evict > 0) {
     if (st->policy == EKV_POLICY_NONE) return EKV_E_ARG;
@@ -332,8 +344,9 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
       return EKV_E_ARG;
   }
   const ekv_step layout = defer_layout_step(st);
-  EkvWs ws = ekv_plan_workspace(bank, &layout, workspace);
-  if (ws.bytes > workspace_bytes) return EKV_E_WORKSPACE;
+  // (dry: a non-null dummy base — several tests below read "is this array present" off the carved pointers)
+  EkvWs ws = ekv_plan_workspace(bank, &layout, dry ? reinterpret_cast<void*>(uintptr_t(256)) : workspace);
+  if (!dry && ws.bytes > workspace_bytes) return EKV_E_WORKSPACE;
   if (st->defer_layers > 0) {    // this call's slice of the per-layer arrays
     const size_t rows0 = (size_t)st->defer_index * bank->n_q_heads * n;
     if (ws.logits) ws.logits += rows0 * ws.t_pad;
@@ -422,13 +435,18 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   // whole decode step in one launch when no head has to be split
   if (n == 1 && st->phases == 0 && ws.n_split == 1 &&
       ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, aa.l_pad, st->n_evict, bank->cap, ws.fused_nw)) {
+    if (one_launch) *one_launch = 1;
+    if (dry) return EKV_OK;
     return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, ws.fused_nw, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
 
   // small-row chunk step (configs[1]: stride 8): one launch, logits in LDS, K and V read once
   if (n > 1 && ekv_chunk_lds_supported(bank, st, aa.phys_extent, scored) &&
-      (st->layer_count * bank->n_kv_heads >= 256 || T <= 1024))
+      (st->layer_count * bank->n_kv_heads >= 256 || T <= 1024)) {
+    if (one_launch) *one_launch = 1;
+    if (dry) return EKV_OK;
     return ekv_launch_chunk_lds(aa, sa, bank->head_dim, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+  }
 
   // phases: 0 = whole step; else a bit mask: 1 attention kernel, 2 scorer (fold + score), 4 fold only, 8 scorer
   // without the fold (4 and 8 let the caller run the scorer on a side stream, off the critical path)
@@ -442,6 +460,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
                           rep * n <= 64 && !(st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) &&
                           ekv_score_lds_bytes_nt256(sa) <= 64 * 1024 && st->n_split != -1;
   if (fuse_chunk) sa.skip_fold = 1;
+  if (fuse_chunk && one_launch) *one_launch = 1;
 
   // How the step ends, decided BEFORE anything is launched: a shape no scorer can take must be refused while the bank is
   // still untouched (the attention kernel appends the new rows).
@@ -454,6 +473,7 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   if (wants_scorer && !fold_only && !range_only && !fuse_chunk && !fast_scorer && ekv_score_lds_bytes(sa) > 160 * 1024)
     return EKV_E_UNSUPPORTED;   // even the selection keys alone exceed one CU's LDS (W > ~39 000): see DESIGN.md "size limits"
   if (n == 1 ? !ekv_attn_decode_supported(bank->head_dim, rep) : !ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
+  if (dry) return EKV_OK;
 
   // decode split path whose partials are folded right behind the attention kernel (attention + fold phases, or a step that has
   // nothing to score): the last-arriving split of a head folds them inside the attention kernel — no fold launch
@@ -495,6 +515,18 @@ int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, con
   }
   if (ekv_launch_score_select(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
   return EKV_OK;
+}
+
+extern "C" {
+
+int ekv_step_attend(const ekv_bank* bank, const ekv_step* st, const void* q, const void* k_new, const void* v_new,
+                    void* out, int32_t* evict_ids, const float* rope_cos, const float* rope_sin, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  return step_attend_impl(bank, st, q, k_new, v_new, out, evict_ids, rope_cos, rope_sin, workspace, workspace_bytes, stream, false, nullptr);
+}
+
+int ekv_step_check(const ekv_bank* bank, const ekv_step* st) {
+  return step_attend_impl(bank, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true, nullptr);
 }
 
 int ekv_gather_ordered(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void* k_out,

@@ -98,6 +98,19 @@ class KVBank:
         check(self.lib.ekv_bank_reset(C.byref(self._bank), self._stream()), "ekv_bank_reset")
         self.n_slots = [0] * self.n_layers
         self.extent = [0] * self.n_layers
+        self._defer = None      # (a half-open deferred token step dies with the bank's contents; arrive[] is zeroed by the reset)
+
+    def abort_step(self):
+        """Drop a deferred token step that was opened (``attend(..., defer=True)`` on some layers) but never flushed — a model
+        forward that raised half-way through the stack.  The layers that did attend have written the new token's row into the
+        slot their free list pointed at, but ``n_slots`` has not advanced, so the next step of every layer reuses that very
+        slot: the bank is as it was before the aborted token.  Returns the number of layers that had attended."""
+        d, n = self._defer, 0
+        if d is not None:
+            n, d["pending"], d["t"] = d["pending"], 0, -1
+            if n:   # a launch that died mid-way could leave arrival counters of the in-kernel fold non-zero
+                self.arrive.zero_()
+        return n
 
     def state_init(self, width, mode, stride=1, layer_begin=0, layer_count=None):
         """mode 0 decoding (easykv/easykv.py:242-245); 1 prefill+keep_attention; 2 prefill (:412-416)."""
@@ -243,6 +256,10 @@ class KVBank:
                 check(self.lib.ekv_step_plan(C.byref(self._bank), C.byref(st), C.byref(ns), C.byref(fu)), "ekv_step_plan")
                 st.n_split = ns.value
             st.defer_layers = self.n_layers
+            # the scorer shape of the flush() call (phases = 8 over all layers) is validated NOW, before the first layer's
+            # attention appends a row: a shape only the last call of the token would refuse must not leave the bank half-stepped
+            st.layer_begin, st.layer_count, st.defer_index, st.phases = 0, self.n_layers, 0, 8
+            check(self.lib.ekv_step_check(C.byref(self._bank), C.byref(st)), "ekv_step_check (deferred scorer)")
             need = self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st))
             ids = torch.empty(self.n_layers, self.n_kv_heads, 1, dtype=torch.int32, device=self.device) if st.n_evict > 0 else None
             ws = self._workspace(need)

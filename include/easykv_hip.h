@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define EKV_ABI_VERSION 3
+#define EKV_ABI_VERSION 4
 
 /* kv_policy strings of the reference -> codes (easykv/easykv.py:288-300, :310-362) */
 enum {
@@ -123,7 +123,8 @@ const char *ekv_strerror(int code);
 size_t ekv_workspace_bytes(const ekv_bank *bank, const ekv_step *step);
 
 /* How ekv_step_attend will run (bank, step): *n_split = key-range splits per head, *fused = 1 when the whole
- * step is ONE launch (ekv_decode_fused_kernel), 0 when it is attention kernel + score/select kernel. */
+ * step is ONE launch (the fused decode kernel, the logits-in-LDS chunk kernel, or a chunk step whose scorer runs as the tail
+ * of its attention kernel), 0 when it is an attention launch (two for the two-pass chunk scheme) + fold / scorer launches. */
 int ekv_step_plan(const ekv_bank *bank, const ekv_step *step, int32_t *n_split, int32_t *fused);
 
 /* slot_of_pos <- identity for the whole bank */
@@ -150,6 +151,13 @@ int ekv_state_init(const ekv_bank *bank, int32_t layer_begin, int32_t layer_coun
 int ekv_step_attend(const ekv_bank *bank, const ekv_step *step, const void *q, const void *k_new, const void *v_new,
                     void *out, int32_t *evict_ids, const float *rope_cos, const float *rope_sin, void *workspace,
                     size_t workspace_bytes, void *stream);
+
+/* Dry run of ekv_step_attend (ABI 4): every argument / shape / capability test of the real call for (bank, step), in the same
+ * order, and nothing launched — no data pointer, workspace or stream is needed.  Returns what ekv_step_attend would return
+ * before its first launch (EKV_OK, EKV_E_ARG, EKV_E_UNSUPPORTED).  For callers that split a step over several calls (the
+ * deferred scorer: per-layer phases = 1|4 calls append rows long before the phases = 8 call that scores them), so that a shape
+ * the LAST call would refuse is refused before the FIRST one touches the bank. */
+int ekv_step_check(const ekv_bank *bank, const ekv_step *step);
 
 /* Ordered view: k_out/v_out fp16 [layer_count][n_kv_heads][n_slots][head_dim] <- rows in position order */
 int ekv_gather_ordered(const ekv_bank *bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void *k_out,

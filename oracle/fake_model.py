@@ -39,11 +39,13 @@ class FakeTokenizer:
         return [str(i) for i in ids]
 
 
-def one_hot_logits(positions):
+def one_hot_logits(positions, vocab=VOCAB):
+    """The token predicted after TRUE position ``p`` is ``(p + 1) % vocab``: with a known prompt length the step at which a
+    given token id (e.g. an EOS id) is sampled is known in advance."""
     n = len(positions)
-    logits = torch.full((1, n, VOCAB), -1e4)
+    logits = torch.full((1, n, vocab), -1e4)
     for i, p in enumerate(positions):
-        logits[0, i, (int(p) + 1) % VOCAB] = 0.0
+        logits[0, i, (int(p) + 1) % vocab] = 0.0
     return logits
 
 
@@ -51,8 +53,9 @@ class FakeAttnModel:
     """``core(q, k_all, v_all, mask, layer) -> (o, p)`` is pluggable so the golden generator can
     route the attention through the reference's own ``llama_forward``."""
 
-    def __init__(self, qs, ks, vs, arch="LlamaForCausalLM", streaming=False, dtype=torch.float32, core=None):
+    def __init__(self, qs, ks, vs, arch="LlamaForCausalLM", streaming=False, dtype=torch.float32, core=None, vocab=VOCAB):
         self.qs, self.ks, self.vs = qs.to(dtype), ks.to(dtype), vs.to(dtype)
+        self.vocab = vocab
         n_layers, hq, _, d = qs.shape
         h = ks.shape[1]
         self.config = SimpleNamespace(num_hidden_layers=n_layers, num_attention_heads=hq,
@@ -95,5 +98,5 @@ class FakeAttnModel:
             attns.append(p if output_attentions else None)
         self.outputs_log.append(torch.stack(outs))
         return SimpleNamespace(past_key_values=tuple(new_past) if use_cache else None,
-                               logits=one_hot_logits(pos),
+                               logits=one_hot_logits(pos, self.vocab),
                                attentions=tuple(attns) if output_attentions else None)

@@ -109,7 +109,8 @@ def cuda_to_cpu_shim():
 
 def run_reference(E, core, case, streams):
     qs, ks, vs = streams
-    model = FakeAttnModel(qs, ks, vs, arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False), core=core)
+    model = FakeAttnModel(qs, ks, vs, arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False), core=core,
+                          vocab=case.get("vocab", 16))
     log = []
     orig = (E.truncate_kv_cache_silo, E.truncate_kv_cache_liso, E.truncate_kv_cache)
 
@@ -126,7 +127,7 @@ def run_reference(E, core, case, streams):
         return orig[2](kv, start, end)
 
     E.truncate_kv_cache_silo, E.truncate_kv_cache_liso, E.truncate_kv_cache = silo, liso, plain
-    cfg = dict(case["config"], eos_token_ids=[-1])
+    cfg = dict(case["config"], eos_token_ids=case.get("eos_token_ids", [-1]))
     ids = torch.arange(case["length"]).view(1, -1) % 16
     buf = io.StringIO()
     orig_multinomial = torch.multinomial
@@ -183,8 +184,9 @@ class StabilityProbe:
 
 def run_oracle(case, streams):
     qs, ks, vs = streams
-    model = FakeAttnModel(qs, ks, vs, arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False))
-    cfg = dict(case["config"], eos_token_ids=[-1])
+    model = FakeAttnModel(qs, ks, vs, arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False),
+                          vocab=case.get("vocab", 16))
+    cfg = dict(case["config"], eos_token_ids=case.get("eos_token_ids", [-1]))
     ids = torch.arange(case["length"]).view(1, -1) % 16
     if "rng_seed" in case:
         torch.manual_seed(case["rng_seed"])
@@ -257,6 +259,24 @@ def cases():
         config=dict(budget=0.5, kv_policy="roco", max_new_tokens=2))
     add("ppl_tova_gqa_s40_stream", mode="ppl", stride=40, length=360, streaming=True, dims=dict(L=1, Hq=8, H=2, D=64), arch="MistralForCausalLM",
         config=dict(budget=0.5, kv_policy="tova", streaming=True))
+    # EOS branch (easykv/easykv.py:257-263, :508-513, :670-676): the reference stops BEFORE feeding an EOS token and its
+    # printed counts depend on where that happens.  The fake model predicts token (p + 1) % vocab after true position p, so
+    # with vocab = 128 the i-th sampled token (0-based) is prompt_length + i and an EOS id picks the step.
+    v = dict(vocab=128)
+    add("dec_roco_eos_mid", mode="decoding", length=16, eos_token_ids=[73], **v,          # 58 tokens sampled, 57 fed, 17 evictions
+        config=dict(budget=40, kv_policy="roco", max_new_tokens=90))
+    add("dec_roco_eos_edge", mode="decoding", length=16, eos_token_ids=[99, 63], **v,     # 48 tokens (a multiple of 16), 2 EOS ids
+        config=dict(budget=40, kv_policy="roco", max_new_tokens=90))
+    add("dec_tova_eos_first", mode="decoding", length=16, eos_token_ids=[16], **v,        # the very first sampled token is the EOS
+        config=dict(budget=40, kv_policy="tova", max_new_tokens=90))
+    add("dec_recency_eos", mode="decoding", length=16, eos_token_ids=[66], **v,           # 51 tokens, range evictions
+        config=dict(budget=40, kv_policy="recency", max_new_tokens=90))
+    add("enc_roco_s4_eos", mode="encoding", stride=4, length=100, eos_token_ids=[104], **v,   # 5 of 12 tokens
+        config=dict(budget=0.5, kv_policy="roco", max_new_tokens=12, **r3))
+    add("auto_roco_s4_eos", mode="auto", stride=4, length=96, eos_token_ids=[108], **v,    # 13 of 24 tokens
+        config=dict(budget=40, kv_policy="roco", max_new_tokens=24, **r3))
+    add("auto_to_decoding_eos", mode="auto", stride=4, length=20, eos_token_ids=[70], **v,  # budget > length: decoding rules, 51 tokens
+        config=dict(budget=60, kv_policy="roco", max_new_tokens=70))
     return out
 
 
@@ -317,7 +337,8 @@ def main():
         meta = dict(name=case["name"], mode=case["mode"], stride=case["stride"], length=case["length"], dims=d,
                     config=case["config"], seed=case["seed"], arch=case.get("arch", "LlamaForCausalLM"), streaming=case.get("streaming", False),
                     printed=printed, result=(res if isinstance(res, float) else str(res)), n_forwards=len(outs), rng_seed=case.get("rng_seed"),
-                    tie_free=probe.unstable == 0, n_selections=probe.n, n_unstable=probe.unstable)
+                    tie_free=probe.unstable == 0, n_selections=probe.n, n_unstable=probe.unstable,
+                    eos_token_ids=case.get("eos_token_ids", [-1]), vocab=case.get("vocab", 16))
         np.savez_compressed(os.path.join(OUT, case["name"] + ".npz"), meta=json.dumps(meta),
                             qs=streams[0].numpy(), ks=streams[1].numpy(), vs=streams[2].numpy(),
                             evict_kinds=kinds, evict_ids=ph, evict_k=ek, evict_ranges=rg, out_lens=out_lens, outputs=out_cat)

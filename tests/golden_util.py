@@ -23,6 +23,11 @@ def load_golden(name):
     return g
 
 
+def eos_ids(meta):
+    """The EOS ids the reference run of this fixture used ([-1] = never stops early) and the fake model's vocabulary."""
+    return meta.get("eos_token_ids", [-1]), meta.get("vocab", 16)
+
+
 def split_ids(g):
     """-> list over per-head eviction steps of int arrays [L,H,k] (sorted along k)."""
     out, off = [], 0

@@ -13,7 +13,7 @@ from oracle.fake_model import FakeTokenizer, one_hot_logits
 
 
 class NativeFakeModel:
-    def __init__(self, qs, ks, vs, device="cuda", arch="LlamaForCausalLM", shard=None):
+    def __init__(self, qs, ks, vs, device="cuda", arch="LlamaForCausalLM", shard=None, vocab=16):
         self.qs, self.ks, self.vs = qs.to(device).half(), ks.to(device).half(), vs.to(device).half()
         n_layers, hq, _, d = qs.shape
         self.config = SimpleNamespace(num_hidden_layers=n_layers, num_attention_heads=hq, num_key_value_heads=ks.shape[1],
@@ -23,6 +23,7 @@ class NativeFakeModel:
         self.outputs_log = []      # per forward: attention outputs of the layers THIS process ran [layers, Hq, n, D]
         self.hidden_log = []       # per forward: the stage output this process produced [1, n, Hq*D]
         self.layer_shard = shard
+        self.vocab = vocab
         if shard is not None:
             from easykv_amd.dist import PipelineStage
             self.stage = PipelineStage(shard)
@@ -45,4 +46,4 @@ class NativeFakeModel:
             self.stage.send_hidden(hidden)
         self.outputs_log.append(torch.stack(outs).float().cpu())
         self.hidden_log.append(hidden.cpu())
-        return SimpleNamespace(logits=one_hot_logits(pos.cpu()).to(self.device))
+        return SimpleNamespace(logits=one_hot_logits(pos.cpu(), self.vocab).to(self.device))

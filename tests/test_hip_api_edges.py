@@ -109,3 +109,50 @@ def test_overlapped_scorer_matches_inline_scorer():
     torch.cuda.synchronize()
     assert torch.equal(banks[0].slot_of_pos, banks[1].slot_of_pos)
     assert torch.equal(banks[0].score_sum, banks[1].score_sum)
+
+
+def test_hipgraph_is_refused_on_a_layer_sharded_model():
+    """A captured forward would contain the stage hand-off (dist.send / dist.recv): refused up front."""
+    from easykv_amd.dist import LayerShard
+    model = _model(16)
+    model.layer_shard = LayerShard(0, 2, 2)
+    with pytest.raises(ValueError, match="hipgraph"):
+        _run(model, "decoding", 1, 16, budget=24, kv_policy="roco", max_new_tokens=4, hipgraph=True)
+    model.layer_shard = LayerShard(0, 4, 2)          # more ranks than layers: some rank would own nothing
+    with pytest.raises(ValueError, match="at least one"):
+        _run(model, "decoding", 1, 16, budget=24, kv_policy="roco", max_new_tokens=4)
+
+
+def test_a_forward_that_raises_mid_stack_does_not_wedge_the_bank():
+    """layers that attended with defer=True before the model raised left 'pending' > 0 and every later deferred
+    attend refused.  begin_forward / abort_step drop the half-open token step; the bank then behaves as if the aborted token
+    had never been issued (the appended row sits in the slot the next token of that layer overwrites)."""
+    from easykv_amd import KVBank, StepPlan, _lib
+    L, Hq, H, D, T0, budget = 3, 8, 8, 64, 200, 199
+    g = torch.Generator().manual_seed(21)
+    k0, v0 = torch.randn(L, H, T0, D, generator=g).half().cuda(), torch.randn(L, H, T0, D, generator=g).half().cuda()
+    banks = [KVBank(L, Hq, H, D, cap=T0 + 8) for _ in range(2)]
+    for b in banks:
+        b.load_rows(k0, v0)
+        b.state_init(budget + 1, 0)
+    plan = StepPlan(policy="roco", phase="decode", evict=True, budget=budget)
+    junk = [torch.randn(1, h, 1, D, generator=g).half().cuda() for h in (Hq, H, H)]
+    banks[1].attend(plan, *junk, layer_begin=0, defer=True)      # token step opened on layer 0 only ... and the model raises
+    with pytest.raises(_lib.EkvError, match="1 of 3 layers"):
+        banks[1].flush()
+    assert banks[1].abort_step() == 1 and banks[1].abort_step() == 0
+    for step in range(6):
+        q, k, v = (torch.randn(L, h, 1, D, generator=g).half().cuda() for h in (Hq, H, H))
+        ids = []
+        for b in banks:
+            for l in range(L):
+                b.attend(plan, q[l:l + 1], k[l:l + 1], v[l:l + 1], layer_begin=l, defer=True)
+            ids.append(b.flush().clone())
+        assert torch.equal(ids[0], ids[1])
+    torch.cuda.synchronize()
+    assert torch.equal(banks[0].score_sum, banks[1].score_sum) and banks[0].n_slots == banks[1].n_slots
+    ka, kb = banks[0].ordered_kv()[0], banks[1].ordered_kv()[0]
+    assert torch.equal(ka, kb)
+    banks[1].attend(plan, *junk, layer_begin=0, defer=True)
+    banks[1].reset()                                              # reset() also forgets a half-open step
+    assert banks[1]._defer is None

@@ -30,7 +30,7 @@ def _replay_decoding(g, n_split=0):
     bank.state_init(budget + 1, 0)
     known = policy in ("roco", "h2o_head", "tova", "recency", "random", "full")
     ids_log, outs = [], []
-    for i in range(max_new):
+    for i in range(m["n_forwards"] - 1):     # the reference's decode forwards (fewer than max_new_tokens when it met an EOS)
         t = P + i
         gen = bank.n_slots[0] + 1 - P
         evict = gen > budget and policy != "full" and known   # unknown strings evict nothing

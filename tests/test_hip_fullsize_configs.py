@@ -149,3 +149,20 @@ def test_config3_vicuna_passkey_stride96_full_geometry():
     assert tr.report.strip() == "KV cache budget ratio: 50.05%(5002/9994)"
     assert tr.cache_len == 5002 + 3
     assert res == " ".join(str(t) for t in tr.result)
+
+
+def test_config1_llama_prefill_stride8_full_geometry():
+    """configs[1]: Llama2-7B prefill mode, S=4096, stride 8, budget 0.5, kv_policy roco -> budget'=2056, idx=2056, r_idx=2048,
+    W=2064: the dense 2048-token causal prefix, then ALL 256 chunk steps of 8 queries per head over a cache
+    oscillating 2056 <-> 2064 (easykv/easykv.py:367-503) through ``generate``, then plain decode.  One layer, Hq=H=32, D=128: a
+    decoder stack issues one layer per call, 32 heads per launch, which the library runs as key-range splits of the MFMA chunk
+    kernel + the scorer; the 32-layers-per-launch form of the same step (the logits-in-LDS kernel, what bench.py times) is
+    compared with the oracle at this geometry by tests/test_hip_fullsize.py::test_chunk_steps_full_size_c2_shape."""
+    from easykv_amd import geometry
+    assert geometry("encoding", 4096, 0.5, 8) == (2056, 2056, 2048)
+    cfg = dict(budget=0.5, kv_policy="roco", max_new_tokens=3, temp_length=4, recent_ratio=0.1)
+    res, tr, frac = _run_pair("encoding", 8, cfg, 1, 32, 32, 128, 4096, seed=4096)
+    assert tr.report.strip() == "KV cache budget ratio: 50.20%(2056/4096)"
+    assert len([e for e in tr.evictions if e["kind"] == "per_head"]) == 256
+    assert tr.cache_len == 2056 + 3
+    assert res == " ".join(str(t) for t in tr.result)

@@ -5,6 +5,7 @@ Checks: the reference's printed budget line, the evicted position sets of every 
 forward's attention outputs (<= 1e-3), and the perplexity."""
 import contextlib
 import io
+import re
 
 import numpy as np
 import pytest
@@ -35,8 +36,8 @@ def test_generate_matches_reference(name, chunk_scheme):
     from tests.native_fake_model import NativeFakeModel
     g = load_golden(name)
     m = g["meta"]
-    model = NativeFakeModel(*g["streams"], arch=m["arch"])
-    cfg = dict(m["config"], eos_token_ids=[-1], _record_evictions=True)
+    model = NativeFakeModel(*g["streams"], arch=m["arch"], vocab=m.get("vocab", 16))
+    cfg = dict(m["config"], eos_token_ids=m.get("eos_token_ids", [-1]), _record_evictions=True)
     ids = torch.arange(m["length"]).view(1, -1) % 16
     buf = io.StringIO()
     if m.get("rng_seed") is not None:
@@ -69,3 +70,71 @@ def test_generate_matches_reference(name, chunk_scheme):
     assert len(ours) == len(ref)
     for step, (a, b) in enumerate(zip(ours, ref)):
         assert np.array_equal(a, b), f"eviction ids differ at eviction {step}"
+
+
+# ---- the EOS branch (easykv/easykv.py:257-263, :508-513, :670-676): the reference tests every sampled token BEFORE feeding it,
+# and the counts of its printed line (:365, :751) depend on where it stops.  The *_eos* fixtures were produced by the real
+# reference with an EOS id the one-hot fake model emits at a known step.
+def _eos_cases():
+    return [n for n in golden_names() if load_golden(n)["meta"].get("eos_token_ids", [-1]) != [-1]]
+
+
+def _ref_evictions(g, shape_of):
+    ref_ph, ref_rg, ref = split_ids(g), g["ranges"].tolist(), []
+    for kind in g["kinds"]:
+        if kind == 0:
+            ref.append(ref_ph.pop(0))
+        else:
+            lo, hi = ref_rg.pop(0)
+            ref.append(np.broadcast_to(np.arange(lo, hi, dtype=np.int32), shape_of(len(ref))))
+    return ref
+
+
+@pytest.mark.parametrize("eos_poll", [None, 1, 4, 16])
+@pytest.mark.parametrize("name", _eos_cases())
+def test_eos_branch_matches_reference(name, eos_poll):
+    """eos_poll = 1 (the default) is the reference's control flow: same text, same printed line, same number of forwards, same
+    evictions, same final cache length.  eos_poll = N > 1 (opt-in) polls the device-side token log every N tokens: text and
+    printed line are still the reference's, the evictions up to the EOS are the reference's, and the host synchronised at most
+    once per N sampled tokens."""
+    import math
+    import easykv_amd
+    from tests.native_fake_model import NativeFakeModel
+    g = load_golden(name)
+    m = g["meta"]
+    model = NativeFakeModel(*g["streams"], arch=m["arch"], vocab=m["vocab"])
+    cfg = dict(m["config"], eos_token_ids=m["eos_token_ids"], _record_evictions=True)
+    if eos_poll is not None:
+        cfg["eos_poll"] = eos_poll
+    poll = eos_poll or 1
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res, cache = easykv_amd.generate(model, torch.arange(m["length"]).view(1, -1) % 16, cfg, kv_mode=m["mode"], stride=m["stride"],
+                                         return_cache=True)
+    assert buf.getvalue().strip() == m["printed"]
+    assert res == m["result"]
+    n_tokens = len(m["result"].split())
+    assert n_tokens < m["config"]["max_new_tokens"]            # the fixture really stopped at the EOS
+    ours = [np.sort(torch.stack(e).cpu().numpy(), axis=-1) for e in cache.evictions]
+    ref = _ref_evictions(g, lambda i: ours[i].shape)
+    assert len(ours) >= len(ref)
+    for step, (a, b) in enumerate(zip(ours, ref)):
+        assert np.array_equal(a, b), f"eviction ids differ at eviction {step}"
+    ref_out = split_outputs(g)
+    for f, (a, b) in enumerate(zip(model.outputs_log, ref_out)):
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=OUT_TOL / 2, atol=OUT_TOL), (f, float((a - b).abs().max()))
+    assert cache.host_syncs <= math.ceil(cache.tokens_sampled / poll) + 1
+    if poll == 1:      # nothing ran past the EOS: forwards, evictions and the cache handed back are the reference's
+        assert len(model.outputs_log) == len(ref_out) == m["n_forwards"]
+        assert len(ours) == len(ref)
+        assert cache.tokens_sampled == n_tokens and cache.host_syncs == n_tokens
+        num = int(re.search(r"[\(\[](\d+)/", m["printed"]).group(1))
+        if m["mode"] == "decoding" or (m["mode"] == "auto" and m["printed"].startswith("KV cache budget ratio")):
+            expect = num + m["length"]          # :364-365 prints the generated slots kept
+        elif m["mode"] == "encoding":
+            expect = num + n_tokens - 1         # :503 prints the cache after the prefill; every fed token is appended (no EOS fed)
+        else:
+            expect = num                        # :749-751 prints the whole cache
+        assert cache.get_seq_length() == expect
+    else:
+        assert cache.tokens_sampled <= min(m["config"]["max_new_tokens"], (n_tokens + poll - 1) // poll * poll)

@@ -21,10 +21,10 @@ def _gen(name, model_hook=None, **extra):
     from tests.native_fake_model import NativeFakeModel
     g = load_golden(name)
     m = g["meta"]
-    model = NativeFakeModel(*g["streams"], arch=m["arch"])
+    model = NativeFakeModel(*g["streams"], arch=m["arch"], vocab=m.get("vocab", 16))
     if model_hook is not None:
         model_hook(model)
-    cfg = dict(m["config"], eos_token_ids=[-1], _record_evictions=True, **extra)
+    cfg = dict(m["config"], eos_token_ids=m.get("eos_token_ids", [-1]), _record_evictions=True, **extra)
     with contextlib.redirect_stdout(io.StringIO()) as buf:
         res, cache = easykv_amd.generate(model, torch.arange(m["length"]).view(1, -1) % 16, cfg, kv_mode=m["mode"], stride=m["stride"],
                                          return_cache=True)

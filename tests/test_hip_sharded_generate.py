@@ -32,8 +32,8 @@ def _run(name, shard, extra_cfg=None):
     from tests.native_fake_model import NativeFakeModel
     g = load_golden(name)
     m = g["meta"]
-    model = NativeFakeModel(*g["streams"], arch=m["arch"], device="cuda:0", shard=shard)
-    cfg = dict(m["config"], eos_token_ids=[-1], _record_evictions=True, **(extra_cfg or {}))
+    model = NativeFakeModel(*g["streams"], arch=m["arch"], device="cuda:0", shard=shard, vocab=m.get("vocab", 16))
+    cfg = dict(m["config"], eos_token_ids=m.get("eos_token_ids", [-1]), _record_evictions=True, **(extra_cfg or {}))
     ids = torch.arange(m["length"]).view(1, -1) % 16
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):

@@ -40,7 +40,7 @@ def test_abi_exports_every_declared_symbol():
     raw = ctypes.CDLL(_build.LIB)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.ekv_abi_version() == 3
+    assert lib.ekv_abi_version() == 4
     assert b"workspace" in lib.ekv_strerror(-3)
     # argument checking happens before any device access: callable without a GPU
     assert lib.ekv_workspace_bytes(None, None) == 0
@@ -142,3 +142,62 @@ def test_active_cache_is_context_local():
     assert seen == [None] and api.active_cache() == "mine"
     api._ACTIVE.reset(tok)
     assert api.active_cache() is None
+
+
+def test_sampler_matches_reference_fixture():
+    """api.logits_adapter (scatter form) against the reference's logits_adapter (easykv/easykv.py:115-134: temperature, top-p
+    mask ``cumsum - p > top_p``, renormalise, un-sort by a second sort + gather), on (logits, temperature, top_p) -> final_prob
+    vectors produced by the imported reference (oracle/gen_sampler_golden.py).  Same torch ops on the same values in the same
+    order per element, so the bar is bit-exact."""
+    import numpy as np
+    from easykv_amd.api import logits_adapter
+    z = np.load(os.path.join(ROOT, "tests", "golden", "sampler", "logits_adapter.npz"))
+    keys = sorted({k.rsplit("|", 1)[0] for k in z.files})
+    assert len(keys) == 45
+    seen_tp = set()
+    for key in keys:
+        name, temperature, top_p = key.split("|")
+        logits = torch.from_numpy(z[key + "|logits"])
+        final, raw = logits_adapter(logits, float(temperature), float(top_p))
+        ref_final, ref_raw = torch.from_numpy(z[key + "|final"]), torch.from_numpy(z[key + "|raw"])
+        assert final.shape == ref_final.shape
+        assert torch.equal(final, ref_final), (key, float((final - ref_final).abs().max()))
+        assert torch.equal(raw.reshape(ref_raw.shape), ref_raw), key
+        # what the fixture exercises: the nucleus really cuts (zeros) for top_p < 1 and rows still sum to 1
+        assert torch.allclose(final.sum(-1), torch.ones(final.shape[:-1]), atol=1e-5)
+        if float(top_p) < 1.0 and float(temperature) > 1e-3 and name != "flat_v33":
+            assert int((final == 0).sum()) > 0
+        seen_tp.add((float(temperature), float(top_p)))
+    assert {(0.7, 0.3), (0.7, 0.9), (1.0, 0.3), (1.0, 0.9), (1.0, 1.0)} <= seen_tp
+
+
+def _fake_bank_step(head_dim=128, hq=32, h=32, cap=2112, n_layers=2, **step):
+    from easykv_amd._lib import Bank, Step
+    bank = Bank(256, 256, 256, 256, 256, 256, n_layers, hq, h, head_dim, cap, None)     # (never dereferenced by a dry run)
+    st = Step()
+    st.layer_begin, st.layer_count, st.q_len, st.n_slots, st.score_off = 0, n_layers, 1, 2049, 0
+    st.policy, st.accumulate, st.n_evict, st.roco_k1, st.roco_tail, st.range_start = 2, 1, 1, 1434, 10, -1
+    st.causal, st.count_add, st.sm_div = 1, 1.0, head_dim ** 0.5
+    for k, v in step.items():
+        setattr(st, k, v)
+    return bank, st
+
+
+def test_step_check_is_a_dry_run_of_step_attend():
+    """ekv_step_check (ABI 4): the argument / shape tests of ekv_step_attend without a launch — callable without a GPU."""
+    from easykv_amd import _lib
+    lib = _lib.load()
+    ok = lambda b, s: lib.ekv_step_check(ctypes.byref(b), ctypes.byref(s))
+    assert ok(*_fake_bank_step()) == 0                                        # the north-star decode step
+    assert ok(*_fake_bank_step(q_len=8, n_slots=2064, n_evict=8, roco_k1=1847, win_lo=4, win_tail=205)) == 0   # configs[1] chunk
+    assert ok(*_fake_bank_step(head_dim=48)) == -2                            # EKV_E_UNSUPPORTED: head_dim not built
+    assert ok(*_fake_bank_step(roco_k1=4000)) == -1                           # roco_k1 > W
+    assert ok(*_fake_bank_step(n_slots=4000)) == -1                           # T > cap
+    assert ok(*_fake_bank_step(policy=4, range_start=-1)) == -1               # range policy without a range
+    assert ok(*_fake_bank_step(layer_count=3)) == -1
+    # deferred scorer: the flush() shape (phases = 8 over all layers) is checked before the first per-layer call
+    assert ok(*_fake_bank_step(defer_layers=2, n_split=8, phases=8)) == 0
+    assert ok(*_fake_bank_step(defer_layers=2, n_split=0, phases=8)) == -1    # deferred steps need an explicit split count
+    # score rows wider than any scorer's LDS (W > ~39 000 columns) are refused before anything is launched
+    assert ok(*_fake_bank_step(cap=60032, n_slots=60000, roco_k1=30000, n_split=-1)) == -2
+    assert lib.ekv_step_check(None, None) == -1

@@ -7,7 +7,7 @@ import torch
 
 from oracle import easykv_oracle as O
 from oracle.fake_model import FakeAttnModel
-from tests.golden_util import golden_names, load_golden, split_ids, split_outputs, trace_events
+from tests.golden_util import eos_ids, golden_names, load_golden, split_ids, split_outputs, trace_events
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -15,8 +15,9 @@ def test_oracle_reproduces_reference(name):
     g = load_golden(name)
     m = g["meta"]
     qs, ks, vs = g["streams"]
-    model = FakeAttnModel(qs, ks, vs, arch=m["arch"], streaming=m["streaming"])
-    cfg = dict(m["config"], eos_token_ids=[-1])
+    eos, vocab = eos_ids(m)
+    model = FakeAttnModel(qs, ks, vs, arch=m["arch"], streaming=m["streaming"], vocab=vocab)
+    cfg = dict(m["config"], eos_token_ids=eos)
     ids = torch.arange(m["length"]).view(1, -1) % 16
     if m.get("rng_seed") is not None:      # kv_policy='random': the reference's draws come from the seeded global CPU generator
         torch.manual_seed(m["rng_seed"])

@@ -73,7 +73,7 @@ def main():
     def run(n):
         with contextlib.redirect_stdout(io.StringIO()) as buf:
             model.easykv_generate(input_ids=ids, generation_config=dict(budget=args.budget, kv_policy="roco", max_new_tokens=n,
-                                                                        temperature=1.0, eos_token_ids=[-1], hipgraph=use_graph))
+                                                                        temperature=1.0, eos_token_ids=[-1], eos_poll=16, hipgraph=use_graph))
         return buf.getvalue().strip()
 
     timed(lambda: run(4))
