@@ -153,9 +153,14 @@ class BudgetedKVCache:
         q = q.to(torch.float16).contiguous()
         k = k.to(torch.float16).contiguous()
         v = v.to(torch.float16).contiguous()
-        if self.score_prefix and n > PREFIX_BLOCK:
-            # keep_attention: the dense prefix must also feed the score rows (easykv/easykv.py:173-186); it is
-            # processed in query blocks so the r x r probability matrix is never materialised
+        rep = self.bank.n_q_heads // self.bank.n_kv_heads
+        wide_two_pass = not self.streaming and rep in (1, 2, 4) and self.bank.head_dim in (64, 128)   # (ekv_chunk_wide's rule)
+        if self.score_prefix and n > PREFIX_BLOCK and not wide_two_pass:
+            # keep_attention: the dense prefix must also feed the score rows (easykv/easykv.py:173-186).  ONE launch per layer
+            # when the step can run as a statistics pass + an exact pass with in-kernel column sums (below: the query blocks are
+            # walked inside the launch by the wide-block kernel and nothing of size r x r exists anywhere); the other kernels
+            # (RoPE-on-read, GQA factors above 4, head_dim 32) export logits or one column-sum row per query block to a workspace,
+            # so there the prefix is cut into query blocks here
             outs = []
             for i0 in range(0, n, PREFIX_BLOCK):
                 o, _ = self.bank.attend(plan, q[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), k[:, :, i0:i0 + PREFIX_BLOCK].contiguous(),
@@ -547,6 +552,9 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
             result = DS.broadcast_object(result, last_rank)
     else:
         raise ValueError(f"unknown kv_mode {kv_mode!r}")
+    if shard is not None:       # stage outputs still in flight (easykv_amd.dist.PipelineStage posts them without waiting)
+        from . import dist as DS
+        DS.drain_stages()
     return (result, cache) if return_cache else result
 
 

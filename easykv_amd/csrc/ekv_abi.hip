@@ -196,14 +196,25 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   int rows = (int)ekv_align((size_t)(T + n_split - 1) / n_split, wg_unit);
   w.rows_per_split = rows;
   w.n_split = (T + rows - 1) / rows;
-  w.n_partials = st->q_len == 1 ? w.n_split : 2 * w.n_split;
+  w.two_pass = ekv_chunk_two_pass(rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass) ? 1 : 0;
+  w.wide = ekv_chunk_wide(bank->head_dim, rep, st->q_len, st->rope_on_read != 0, w.two_pass != 0,
+                          !w.two_pass && scored && st->accumulate != 0) ? 1 : 0;
+  // partials per query row: one per split (decode, wide chunk kernel) or one per split and key half (16x16 chunk kernel)
+  w.n_partials = (st->q_len == 1 || w.wide) ? w.n_split : 2 * w.n_split;
   const size_t rowsq = (size_t)st->layer_count * bank->n_q_heads * st->q_len;
   size_t off = 0;
   char* p = static_cast<char*>(base);
   w.logits = nullptr;
   w.stats = w.colsum = nullptr;
-  w.two_pass = ekv_chunk_two_pass(rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass) ? 1 : 0;
-  w.n_col_parts = ekv_chunk_col_parts(qpw, st->rope_on_read != 0) * w.n_qblocks;   // query-tile waves per workgroup x query blocks
+  // column-sum partial rows per head: query-tile waves per workgroup x query blocks; the wide kernel combines them itself
+  if (w.wide) {
+    // the exact pass of the wide kernel walks the query blocks of a (head, key range) inside the workgroup and leaves ONE row of
+    // column sums; a launch of few (head, layer) pairs (one layer of a decoder stack) spreads them over up to 16 workgroups
+    const int wgs = st->layer_count * bank->n_kv_heads * w.n_split;
+    w.n_col_parts = std::max(1, std::min(std::min(w.n_qblocks, 16), (512 + wgs - 1) / wgs));
+  } else {
+    w.n_col_parts = ekv_chunk_col_parts(qpw, st->rope_on_read != 0) * w.n_qblocks;
+  }
   if (w.two_pass) {   // statistics partials + column sums instead of the logits
     w.stats = reinterpret_cast<float*>(p + off);
     off += ekv_align(rowsq * w.n_partials * 2 * 4, 256);
@@ -218,7 +229,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   w.tova_row = reinterpret_cast<float*>(p + off);
   off += ekv_align((size_t)st->layer_count * w.t_pad * 4, 256);
   w.big_rows = nullptr;
-  if (scored && ekv_score_rows_exceed_lds(T - st->score_off, rep * st->q_len)) {   // W > ~10 000: rows in scratch, keys in LDS
+  if (scored && ekv_score_rows_exceed_lds(T - st->score_off, w.two_pass ? 0 : rep * st->q_len)) {   // W > ~10 000: rows in scratch, keys in LDS
     w.big_rows = reinterpret_cast<float*>(p + off);
     off += ekv_align((size_t)st->layer_count * bank->n_kv_heads * 3 * w.t_pad * 4, 256);
   }

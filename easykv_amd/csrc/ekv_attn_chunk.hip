@@ -1,4 +1,6 @@
 // head_dim dispatch and query-block planning of the chunk (q_len > 1) attention kernels.
+#include <cstdlib>
+
 #include "ekv_common.h"
 #include "ekv_kernels.h"
 
@@ -6,6 +8,10 @@
 EKV_DECL(32, 0) EKV_DECL(32, 1) EKV_DECL(32, 2) EKV_DECL(64, 0) EKV_DECL(64, 1) EKV_DECL(64, 2)
 EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 #undef EKV_DECL
+
+#define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t);
+EKW_DECL(64, 0) EKW_DECL(64, 1) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 1) EKW_DECL(128, 2)
+#undef EKW_DECL
 
 // Two-pass scheme (statistics pass + exact pass with in-kernel column sums, see ekv_attn_chunk.inc) for scored chunk
 // steps.  It trades one extra read of K (and a third MFMA product) for the rep x n x T logits never touching HBM: at rep*n = 96
@@ -37,6 +43,19 @@ void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw
   *n_qblocks = (q_len + rows - 1) / rows;
   const int r = rep * rows;
   *qpw = r <= 32 ? 1 : (r <= 64 ? 2 : 4);
+}
+
+// Wide query blocks (33..128 GQA-folded rows) run on the 32x32x16 kernel of ekv_attn_wide.inc: the dense prefix and every wide
+// strided chunk step are bound by the MFMA kernel itself, not by HBM.  EKV_NO_WIDE=1 in the environment keeps
+// the 16x16x32 kernel (A/B measurements on one box).
+bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, bool wants_logits) {
+  static const bool off = [] { const char* e = std::getenv("EKV_NO_WIDE"); return e != nullptr && e[0] == '1'; }();
+  if (off || rope || q_len < 2 || (head_dim != 64 && head_dim != 128)) return false;
+  int qb_rows, n_qblocks, qpw;
+  ekv_chunk_blocks(rep, q_len, &qb_rows, &n_qblocks, &qpw);
+  if (qpw < 2) return false;                                  // <= 32 rows: HBM-bound shapes, the small-tile kernels
+  if (two_pass) return rep == 1 || rep == 2 || rep == 4;      // the exact pass folds the rep query heads inside a register quad
+  return !wants_logits;
 }
 
 // rope_on_read: q' = q*cos[pos] + rotate_half(q)*sin[pos] with pos = T - n + i (llama_patch.py:311, :326), once per step,
@@ -78,6 +97,16 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
   if (qb_rows != a.qb_rows || n_qblocks != a.n_qblocks) return hipErrorInvalidValue;
   const bool rope = a.rope_cos != nullptr;
+  if (ekv_chunk_wide(head_dim, a.n_q_heads / a.n_kv_heads, a.q_len, rope, two_pass, a.logits != nullptr)) {
+    if (fuse_sc != nullptr || (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts < 1 || a.n_col_parts > n_qblocks))) return hipErrorInvalidValue;
+    const int nwq = qpw == 4 ? 4 : 2;
+#define EKW_GO(d, m) ekv_launch_attn_wide_d##d##_m##m(a, nwq, layer_count, s)
+    hipError_t e = hipSuccess;
+    if (head_dim == 128) { e = two_pass ? EKW_GO(128, 1) : EKW_GO(128, 0); if (two_pass && e == hipSuccess) e = EKW_GO(128, 2); }
+    else { e = two_pass ? EKW_GO(64, 1) : EKW_GO(64, 0); if (two_pass && e == hipSuccess) e = EKW_GO(64, 2); }
+#undef EKW_GO
+    return e;
+  }
   if (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts != ekv_chunk_col_parts(qpw, rope) * n_qblocks)) return hipErrorInvalidValue;
 #define EKV_GO(d, m) ekv_launch_attn_chunk_d##d##_m##m(a, kernel_code(qpw, rope, m), layer_count, s, fuse_sc)
   hipError_t e = hipSuccess;

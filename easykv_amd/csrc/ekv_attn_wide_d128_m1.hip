@@ -1,0 +1,4 @@
+// wide-query-block attention kernel (ekv_attn_wide.inc), head_dim 128, mode 1
+#define EKV_D 128
+#define EKV_WIDE_MODE 1
+#include "ekv_attn_wide.inc"

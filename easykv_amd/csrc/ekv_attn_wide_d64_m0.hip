@@ -1,0 +1,4 @@
+// wide-query-block attention kernel (ekv_attn_wide.inc), head_dim 64, mode 0
+#define EKV_D 64
+#define EKV_WIDE_MODE 0
+#include "ekv_attn_wide.inc"

@@ -17,6 +17,7 @@ struct EkvWs {
   int32_t two_pass, n_col_parts;
   float* row_stats;
   int32_t fold_in_kernel;   // chunk step whose attention kernel writes the final output itself (no partials, no fold)
+  int32_t wide;             // chunk step on the wide-query-block kernel (ekv_attn_wide.inc): ONE partial per split, ONE column-sum row
   int32_t fused_nw;     // waves per workgroup the fused decode kernel would use for this launch (4 or 8)
   __half* q_rot;    // rope_on_read chunk steps: [2][layer_count][Hq][q_len][D] rotated queries, fp16 hi then lo
   int32_t t_pad, n_split, rows_per_split;
@@ -84,6 +85,9 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
 size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs& a);
 bool ekv_score_rows_exceed_lds(int W, int rows);   // generic scorer: S / Q / C + keys of W columns do not fit 160 KB of LDS
 bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode);
+// the launch runs on the wide-query-block kernel (32x32x16 MFMA, ekv_attn_wide.inc): 33..128 GQA-folded rows per query block,
+// plain keys, head_dim 64 / 128, and either the two-pass scheme (rep in {1, 2, 4}) or a step that exports no logits
+bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, bool wants_logits);
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 bool ekv_attn_decode_supported(int head_dim, int rep);

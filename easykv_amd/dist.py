@@ -117,15 +117,36 @@ def broadcast_object(obj, src: int):
     return box[0]
 
 
+_STAGES = []     # every PipelineStage of this process (drain_stages)
+
+
+def drain_stages():
+    """Wait for every stage output this process has posted but whose transfer has not completed (end of a generate)."""
+    for st in _STAGES:
+        st.drain()
+
+
 class PipelineStage:
     """The hand-off of a layer-sharded model: stage r receives the hidden state ``[1, n, hidden]`` of the
     forward in flight from stage r-1, runs its own layer block, and sends the result to stage r+1 — one point-to-point
     transfer per stage boundary and forward, nothing else crosses xGMI (K/V, slot maps and score rows stay with the layer).
     The reference gets the same partition from accelerate's ``device_map='auto'`` hooks (test_passkey.py:25-35), which copy
-    the hidden state between devices — and every layer's probability matrix to one device (llama_patch.py:244-246)."""
+    the hidden state between devices — and every layer's probability matrix to one device (llama_patch.py:244-246).
 
-    def __init__(self, shard: LayerShard):
+    **The strided prefill is a pipeline.**  Chunk i+1's input is the prompt, not chunk i's logits (easykv/easykv.py:426-433),
+    and eviction state is per layer, so stage r may start chunk i+1 while stage r+1 still works on chunk i.  The stage
+    output is therefore POSTED (``isend``) and the stage carries on: up to ``depth`` outputs may be in flight before a stage
+    waits for its successor (one is enough to keep every stage busy; two absorb jitter).  Decode steps resynchronise by
+    themselves — the next token comes from the last stage (easykv_amd.api.generate broadcasts it).  ``run_ahead`` records
+    how many forwards this stage was ahead of the completion of its oldest posted output (evidence for the tests / bench)."""
+
+    def __init__(self, shard: LayerShard, depth: int = 2):
         self.shard = shard
+        self.depth = max(1, depth)
+        self._posted = []          # (request, buffer kept alive) of stage outputs in flight, oldest first
+        self.n_sent = 0
+        self.run_ahead = []        # per send: outputs still in flight right after posting (0 = the successor keeps up)
+        _STAGES.append(self)
 
     @property
     def first(self) -> bool:
@@ -142,8 +163,22 @@ class PipelineStage:
         return recv(torch.empty_like(like), self.shard.rank - 1)
 
     def send_hidden(self, hidden: torch.Tensor):
-        if self.shard.world > 1 and not self.last:
-            send(hidden.contiguous(), self.shard.rank + 1)
+        if self.shard.world == 1 or self.last:
+            return
+        buf = hidden.contiguous()
+        if _needs_host_staging(buf):
+            buf = buf.cpu()            # (gloo: waits for this stage's kernels; RCCL sends the device buffer from the stream)
+        self._posted = [(r, b) for (r, b) in self._posted if not r.is_completed()]
+        while len(self._posted) >= self.depth:      # the successor is `depth` forwards behind: wait for the oldest transfer
+            self._posted.pop(0)[0].wait()
+        self._posted.append((dist.isend(buf, self.shard.rank + 1), buf))
+        self.n_sent += 1
+        self.run_ahead.append(len(self._posted) - 1)
+
+    def drain(self):
+        for req, _ in self._posted:
+            req.wait()
+        self._posted = []
 
 
 def barrier(device=None):

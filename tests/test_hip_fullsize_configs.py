@@ -163,6 +163,6 @@ def test_config1_llama_prefill_stride8_full_geometry():
     cfg = dict(budget=0.5, kv_policy="roco", max_new_tokens=3, temp_length=4, recent_ratio=0.1)
     res, tr, frac = _run_pair("encoding", 8, cfg, 1, 32, 32, 128, 4096, seed=4096)
     assert tr.report.strip() == "KV cache budget ratio: 50.20%(2056/4096)"
-    assert len([e for e in tr.evictions if e["kind"] == "per_head"]) == 256
+    assert len([e for e in tr.evictions if e["kind"] == "per_head"]) == 255      # (the first chunk only fills the cache up to idx)
     assert tr.cache_len == 2056 + 3
     assert res == " ".join(str(t) for t in tr.result)

@@ -16,7 +16,7 @@ if not f:
     print(os.environ["LABEL"], "no counters:", open('/tmp/pp.log').read()[-400:]); raise SystemExit
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
-    if 'ekv_attn_chunk' in r['Kernel_Name'] or 'score_select' in r['Kernel_Name']:
+    if 'ekv_attn_chunk' in r['Kernel_Name'] or 'ekv_attn_wide' in r['Kernel_Name'] or 'score_select' in r['Kernel_Name']:
         acc[r['Kernel_Name'][:72] + ' wg=' + r['Workgroup_Size'] + ' vgpr=' + r['VGPR_Count']][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in acc.items():
     print(os.environ["LABEL"], '|', k, {c: round(sum(x) / len(x) / 1e6, 2) for c, x in v.items()}, '(millions per launch, mean of', len(next(iter(v.values()))), 'launches)')
