@@ -237,6 +237,52 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
             "chunk_steps_timed": n_chunks, "slot_map": "identity" if args.identity_layout else "scattered"}
 
 
+def prefill_pipeline(args, dev, rank, world, DS, S=9994, stride=96, n_chunks=32, warm=6):
+    """N > 1 secondary figure: the chunk phase of BASELINE configs[3] (S=9994, stride 96, budget 0.5, roco: what the reference runs
+    over 8 GPUs with device_map='auto', test_passkey.py:25-38) through the LAYER-SHARDED PIPELINE: rank r owns its LayerShard
+    block of the --layers layers; chunk i's stage output [stride, Hq*D] fp16 goes r -> r+1 point to point (posted, not waited
+    for: easykv_amd.dist.PipelineStage) and stage r starts chunk i+1 meanwhile — chunk i+1's input is the prompt, not chunk i's
+    logits (easykv/easykv.py:426-433), and eviction state is per layer.  value = prompt tokens leaving the last stage per second
+    (barrier + synchronize on both sides, max over ranks)."""
+    from easykv_amd import KVBank, StepPlan, geometry
+    Hq, D = args.heads, args.head_dim
+    H = args.kv_heads or Hq
+    shard = DS.LayerShard(rank, world, args.layers)
+    L = shard.count
+    bp, idx, _ = geometry("encoding", S, 0.5, stride)
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    rnd = lambda h, n: torch.randn(L, h, n, D, generator=g, device=dev).half()
+    bank = KVBank(L, Hq, H, D, cap=idx + stride, device=dev)
+    bank.load_rows(rnd(H, idx), rnd(H, idx))
+    bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=g, device=dev), dim=-1).int()
+    bank.state_init(idx + stride, 2, stride)
+    n_in = warm + n_chunks
+    qs_, ks_, vs_ = [rnd(Hq, stride) for _ in range(n_in)], [rnd(H, stride) for _ in range(n_in)], [rnd(H, stride) for _ in range(n_in)]
+    plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=bp, recent=int(bp * 0.1), sink=4, stride=stride)
+    outs = [torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev) for _ in range(4)]     # (posted outputs stay alive)
+    ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
+    stage = DS.PipelineStage(shard, depth=2)
+    like = torch.zeros(1, stride, Hq * D, dtype=torch.float16, device=dev)
+    t0 = 0.0
+    for i in range(n_in):
+        if i == warm:
+            stage.drain()
+            DS.barrier(dev)
+            t0 = time.perf_counter()
+        stage.recv_hidden(like)                    # the previous stage's output of THIS chunk (first stage: nothing to wait for)
+        out = outs[i % 4]
+        bank.attend(plan, qs_[i], ks_[i], vs_[i], out=out, evict_ids=ids)
+        stage.send_hidden(out[L - 1].transpose(0, 1).reshape(1, stride, Hq * D))      # posted; this stage carries on with chunk i+1
+    stage.drain()
+    DS.barrier(dev)
+    dt = DS.max_over_ranks(time.perf_counter() - t0, dev)
+    return {"workload": f"bench-P chunk phase through the layer pipeline: S={S} stride={stride} budget=0.5 (configs[3] shape), {args.layers} layers over "
+                        f"{world} ranks ({L} on rank {rank}), T={idx + stride}, Hq={Hq} H={H} D={D} roco",
+            "value": n_chunks * stride / dt, "unit": "prompt tokens/s (chunk phase, attention/eviction path only, all stages)",
+            "us_per_chunk_step_pipeline": dt / n_chunks * 1e6, "chunks_timed": n_chunks,
+            "handoff": "isend of the stage output, up to 2 in flight; recv blocking", "max_outputs_in_flight_rank0": max(stage.run_ahead or [0])}
+
+
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (the 2:1-sparsity figure is never used)
 
 
@@ -268,6 +314,75 @@ def dense_prefix(args, dev, S, stride, reps=3):
             "ms": t * 1e3, "value": n / t, "unit": "prompt tokens/s (prefix, attention path only)",
             "roofline": {"bound": "mfma", "achieved": fl / t / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": fl / t / 1e12 / MFMA_F16_PEAK_TFLOPS, "flops": fl, "traffic": None}}
+
+
+def dense_prefix_scored(args, dev, n, kv_heads, stride, label, reps=3):
+    """Secondary figure: the SCORED dense prefix of a strided prefill with keep_attention=True (reference easykv.py:396, :403-405,
+    h2o_head_score :173-186: the prefix's probabilities seed S and Q): one step of ``n`` queries per layer — a statistics pass and
+    an exact pass with in-kernel column sums of the wide-block kernel (the query blocks are walked inside the launch; the r x r map
+    never exists) + the scorer.  flops = the attention's own 4 * Hq * D * n^2 / 2 per layer (causal QK^T and PV); the two-pass
+    scheme executes 1.5x that on the MFMA pipe (QK^T twice)."""
+    from easykv_amd import KVBank, StepPlan
+    L, Hq, D = args.layers, args.heads, args.head_dim
+    H = kv_heads or Hq
+    g = torch.Generator(device=dev).manual_seed(77)
+    q, k, v = (torch.randn(L, h, n, D, generator=g, device=dev).half() for h in (Hq, H, H))
+    out = torch.empty(L, Hq, n, D, dtype=torch.float16, device=dev)
+    plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=False, stride=stride)
+    ms = []
+    for _ in range(reps + 1):
+        bank = KVBank(L, Hq, H, D, cap=n + stride + 8, device=dev)
+        bank.state_init(n + stride, 1, stride)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        bank.attend(plan, q, k, v, out=out)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        ms.append(ev[0].elapsed_time(ev[1]))
+        one_launch_set = bank.step_plan(plan, n)
+        del bank
+    t = sum(ms[1:]) / reps * 1e-3
+    fl = 4.0 * Hq * D * n * n / 2 * L
+    return {"workload": f"scored dense causal prefix ({label}): {n} tokens, L={L} Hq={Hq} H={H} D={D}, keep_attention, statistics pass + exact "
+                        f"pass + scorer over all layers (n_split={one_launch_set[0]})",
+            "ms": t * 1e3, "value": n / t, "unit": "prompt tokens/s (scored prefix, attention path only)",
+            "roofline": {"bound": "mfma", "achieved": fl / t / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / t / 1e12 / MFMA_F16_PEAK_TFLOPS, "flops": fl, "mfma_flops_executed": 1.5 * fl, "traffic": None}}
+
+
+def live_pmc_step(script_args, script, timeout_s=150):
+    """HBM traffic of ONE chunk step whose work is several launches (statistics pass + exact pass + scorer), measured in THIS run:
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` in separate counter-only passes over a short child run of ``script``; the
+    bytes of every launch of the path's kernels are summed and divided by the number of steps (= launches of the scorer, one per
+    step).  gfx950 correction as in live_pmc: 2 x FETCH_SIZE + WRITE_SIZE, KiB.  -> (bytes per step, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    names = ("ekv_attn_wide_kernel", "ekv_attn_chunk_kernel", "ekv_score_select_kernel", "ekv_chunk_lds_kernel")
+    tot, steps = {}, 0
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ekv_pmc_", dir="/tmp")
+        try:
+            subprocess.run([rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, script] + script_args, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == ctr and any(n in r["Kernel_Name"] for n in names)] if fs else []
+        except Exception as e:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"live PMC pass failed ({type(e).__name__})"
+        shutil.rmtree(d, ignore_errors=True)
+        steps = sum(1 for r in rows if "ekv_score_select_kernel" in r["Kernel_Name"])
+        if steps < 4:
+            return None, f"live PMC pass saw {steps} steps"
+        tot[ctr] = sum(float(r["Counter_Value"]) for r in rows) / steps
+    return ((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0,
+            f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_chunk.py {' '.join(script_args)}, "
+            "all launches of a step summed, 2 x FETCH + WRITE (gfx950 correction, KiB -> bytes)")
 
 
 def prefill_pmc(S, stride, L, Hq, H, D, policy):
@@ -642,6 +757,9 @@ def main():
                   "layers_per_rank": r2["L"], "fused": r2["fused"], "n_split": r2["n_split"],
                   "note": "weak: every rank owns a whole 32-layer block (aggregate layer-parallel throughput)" if other == "weak" else
                           "strong: the 32-layer model split over the ranks"}
+    pipe = None
+    if world > 1 and not args.no_prefill and not args.graph and args.layers >= world:
+        pipe = prefill_pipeline(args, dev, rank, world, DS)
     if rank == 0:
         L, H, T, lpl, fused, ev = r["L"], r["H"], r["T"], r["lpl"], r["fused"], r["ev"]
         n_state = {"roco": 3, "h2o_head": 1, "tova": 1}.get(args.policy, 0)
@@ -665,8 +783,16 @@ def main():
             "data": "synthetic", "config": cfg}
         if second is not None:
             line["second_scaling"] = second
+        if pipe is not None:
+            line["strided_prefill_pipeline"] = pipe
         if r["seq"] is not None:
-            line["per_layer_launches"] = {"value": r["seq"], "unit": "tokens/s", "note": "same step issued one layer per call, as a sequential "
+            us_layer = 1e6 / r["seq"] / L      # wall time per layer call (attention + in-kernel fold) incl. its share of the deferred scorer
+            line["per_layer_launches"] = {"value": r["seq"], "unit": "tokens/s", "us_per_layer": us_layer,
+                                          "roofline_step": {"bound": "hbm (latency-bound in practice: one launch of 32 heads per layer)",
+                                                            "achieved": b["total"] / (us_layer * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                            "frac": b["total"] / (us_layer * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                            "bytes_per_layer_step": b["total"], "timing": "host wall clock over whole tokens / layers"},
+                                          "note": "same step issued one layer per call, as a sequential "
                                           "model does: attention + fold per layer, the scorers of all layers in one launch per token; "
                                           "latency-bound; not the headline value"}
         if fused:
@@ -718,7 +844,16 @@ def main():
             line["strided_prefill_more"] = [strided_prefill(args, dev, S=4096, stride=64, n_chunks=24),
                                             strided_prefill(args, dev, S=4096, stride=96, n_chunks=16),
                                             strided_prefill(args, dev, S=9994, stride=96, n_chunks=16)]
+            if not args.no_live_pmc and (args.layers, Hq, H, D, args.policy) == (32, 32, 32, 128, "roco"):
+                # wide strides: a step is several launches (statistics pass, exact pass, scorer) — all of them measured in this run
+                for spm, sargs in ((line["strided_prefill_more"][0], ["4096", "64", "8"]), (line["strided_prefill_more"][2], ["9994", "96", "6"])):
+                    live, live_src = live_pmc_step(sargs, os.path.join(ROOT, "tools", "bench_chunk.py"))
+                    if live is not None:
+                        spm["roofline"].update(traffic=live, traffic_source=live_src, traffic_over_algorithmic=live / spm["roofline"]["bytes_per_step"])
             line["dense_prefix"] = [dense_prefix(args, dev, 4096, 8), dense_prefix(args, dev, 9994, 96)]
+            # scored prefix (keep_attention): BASELINE configs[2] (Mistral GQA, stride 16, budget 0.3: r_idx = 1216) and a 4906-token MHA prefix
+            line["dense_prefix_scored"] = [dense_prefix_scored(args, dev, 1216, 8, 16, "configs[2]: S=4096 stride=16 budget=0.3"),
+                                           dense_prefix_scored(args, dev, 4906, 0, 96, "S=9994 stride=96 budget=0.5")]
         if world == 1 and not args.no_boundary and not args.graph:
             line["boundary_kernels"] = boundary_kernels(args, dev)
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only

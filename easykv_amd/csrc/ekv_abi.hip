@@ -59,36 +59,62 @@ __global__ void ekv_rows_copy_kernel(__half* bank_k, __half* bank_v, const int32
 }
 
 // Reference-shaped physical compaction (easykv/easykv.py:56-82) in place, identity layout.  One workgroup per
-// (tensor, head, layer).  Destination d >= first victim takes source d + #victims <= source; chunks ascend and every
-// chunk is fully read before it is written, so a source row is never overwritten before it has been moved.
+// (tensor, head, layer).  Destination d >= first victim takes source d + #victims <= source: a forward memmove by 1 .. n_evict rows.
+// Chunks of 256 / (D/8) * CH rows ascend; inside a chunk every thread has its source rows in registers before any thread
+// stores (one barrier).  Nothing else needs ordering: chunk c+1 reads rows above everything chunk c writes, and chunk c+1's writes
+// only reach rows chunk c had read before ITS barrier — so the loads of chunk c+1 are issued BEFORE the stores of chunk c
+// (two register sets), no thread ever waits for a store to complete, and there is one barrier per chunk instead of two.
+template <int CH, bool SINGLE>
 __global__ void __launch_bounds__(256) ekv_compact_inplace_kernel(__half* k, __half* v, const int32_t* evict, int n_kv_heads,
                                                                   int cap, int D, int layer_begin, int n_slots, int n_evict) {
   extern __shared__ int32_t s_ev[];
   const int which = blockIdx.x, h = blockIdx.y, ll = blockIdx.z;
-  __half* base = (which == 0 ? k : v) + ((size_t)(layer_begin + ll) * n_kv_heads + h) * cap * D;
+  char* base = reinterpret_cast<char*>((which == 0 ? k : v) + ((size_t)(layer_begin + ll) * n_kv_heads + h) * cap * D);
   for (int i = threadIdx.x; i < n_evict; i += 256) s_ev[i] = evict[((size_t)ll * n_kv_heads + h) * n_evict + i];
   __syncthreads();
   const int lpr = D / 8, sub = threadIdx.x % lpr, rg = threadIdx.x / lpr, rpb = 256 / lpr;
-  constexpr int CH = 4;  // rows per thread per chunk
   const int first = s_ev[0], n_keep = n_slots - n_evict;
-  for (int d0 = first; d0 < n_keep; d0 += rpb * CH) {
-    uint4 buf[CH];
+  const int row_bytes = D * 2;
+  // source row of destination d = d + #{e : ev[e] - e <= d} (ev ascending, so ev[e] - e is non-decreasing: a branch-free binary
+  // search with a launch-uniform number of steps; the single-victim decode step needs none).  Rows past the end are clamped:
+  // the loads are unconditional.
+  int n_bits = 0;
+  while ((1 << n_bits) < n_evict + 1) ++n_bits;
+  auto src_of = [&](int d) __attribute__((always_inline)) {
+    d = min(d, n_keep - 1);
+    if (SINGLE) return d + 1;              // (d >= first; template parameter: no victim walk between the loads of a chunk)
+    int cnt = 0;                           // largest cnt with ev[cnt - 1] - (cnt - 1) <= d
+    for (int b = n_bits - 1; b >= 0; --b) {
+      const int c = cnt + (1 << b);
+      const int e = min(c, n_evict) - 1;
+      cnt = (c <= n_evict && s_ev[e] - e <= d) ? c : cnt;
+    }
+    return d + cnt;
+  };
+  if (first >= n_keep) return;
+  ekv_u4 ra[CH], rb[CH];      // two register sets, roles alternate (a copy nxt -> cur would wait for the look-ahead loads)
+  const int step = rpb * CH;
+  auto load = [&](ekv_u4 (&r)[CH], int d0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) r[c] = __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(base + (size_t)src_of(d0 + c * rpb + rg) * row_bytes + sub * 16));
+  };
+  auto store = [&](const ekv_u4 (&r)[CH], int d0) __attribute__((always_inline)) {
+    // every thread's rows of THIS chunk have landed (the CH newer loads stay in flight), then the stores
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int d = d0 + c * rpb + rg;
-      if (d < n_keep) {
-        int src = d;
-        for (int e = 0; e < n_evict && s_ev[e] <= src; ++e) src++;
-        buf[c] = reinterpret_cast<const uint4*>(base + (size_t)src * D)[sub];
-      }
+      if (d < n_keep) __builtin_nontemporal_store(r[c], reinterpret_cast<ekv_u4*>(base + (size_t)d * row_bytes + sub * 16));
     }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int d = d0 + c * rpb + rg;
-      if (d < n_keep) reinterpret_cast<uint4*>(base + (size_t)d * D)[sub] = buf[c];
-    }
-    __syncthreads();
+  };
+  load(ra, first);
+  for (int d0 = first; d0 < n_keep; d0 += 2 * step) {
+    load(rb, d0 + step);
+    store(ra, d0);
+    load(ra, d0 + 2 * step);
+    store(rb, d0 + step);
   }
 }
 
@@ -578,9 +604,12 @@ int ekv_compact_inplace(const ekv_bank* bank, int32_t layer_begin, int32_t layer
   if (int e = check_layers(bank, layer_begin, layer_count)) return e;
   if (!evict_ids || n_evict <= 0 || n_evict >= n_slots || n_slots > bank->cap) return EKV_E_ARG;
   drop_stale_error();
-  hipLaunchKernelGGL(ekv_compact_inplace_kernel, dim3(2, bank->n_kv_heads, layer_count), dim3(256), (size_t)n_evict * 4,
-                     static_cast<hipStream_t>(stream), static_cast<__half*>(bank->k), static_cast<__half*>(bank->v),
-                     evict_ids, bank->n_kv_heads, bank->cap, bank->head_dim, layer_begin, n_slots, n_evict);
+  static const int ch = [] { const char* e = std::getenv("EKV_COMPACT_CH"); return e ? std::atoi(e) : 16; }();   // (tuning knob; 4 / 8 / 16 rows per thread in flight: 4.3 / 4.5 / 4.65 TB/s)
+#define EKV_CI(CHV) hipLaunchKernelGGL((n_evict == 1 ? ekv_compact_inplace_kernel<CHV, true> : ekv_compact_inplace_kernel<CHV, false>), dim3(2, bank->n_kv_heads, layer_count), dim3(256), (size_t)n_evict * 4, \
+                     static_cast<hipStream_t>(stream), static_cast<__half*>(bank->k), static_cast<__half*>(bank->v),                      \
+                     evict_ids, bank->n_kv_heads, bank->cap, bank->head_dim, layer_begin, n_slots, n_evict)
+  if (ch <= 2) EKV_CI(2); else if (ch <= 4) EKV_CI(4); else if (ch <= 8) EKV_CI(8); else EKV_CI(16);
+#undef EKV_CI
   return launch_status();
 }
 

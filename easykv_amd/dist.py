@@ -9,6 +9,7 @@ same code runs on ``gloo`` for the CPU tests.
 from __future__ import annotations
 
 import os
+import time
 from dataclasses import dataclass
 
 import torch
@@ -146,6 +147,7 @@ class PipelineStage:
         self._posted = []          # (request, buffer kept alive) of stage outputs in flight, oldest first
         self.n_sent = 0
         self.run_ahead = []        # per send: outputs still in flight right after posting (0 = the successor keeps up)
+        self.t_recv, self.t_send = [], []      # host clock (time.time) when forward i's input had arrived / its output was posted
         _STAGES.append(self)
 
     @property
@@ -159,11 +161,15 @@ class PipelineStage:
     def recv_hidden(self, like: torch.Tensor) -> torch.Tensor:
         """Stage input: ``like`` itself on the first stage, else the previous stage's output (same shape / dtype)."""
         if self.shard.world == 1 or self.first:
+            self.t_recv.append(time.time())
             return like
-        return recv(torch.empty_like(like), self.shard.rank - 1)
+        got = recv(torch.empty_like(like), self.shard.rank - 1)
+        self.t_recv.append(time.time())
+        return got
 
     def send_hidden(self, hidden: torch.Tensor):
         if self.shard.world == 1 or self.last:
+            self.t_send.append(time.time())
             return
         buf = hidden.contiguous()
         if _needs_host_staging(buf):
@@ -174,6 +180,7 @@ class PipelineStage:
         self._posted.append((dist.isend(buf, self.shard.rank + 1), buf))
         self.n_sent += 1
         self.run_ahead.append(len(self._posted) - 1)
+        self.t_send.append(time.time())
 
     def drain(self):
         for req, _ in self._posted:
