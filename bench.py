@@ -403,7 +403,7 @@ def prefill_pmc(S, stride, L, Hq, H, D, policy):
         one = [v for n, v in ks.items() if "ekv_chunk_lds_kernel" in n or ("ekv_attn_chunk_kernel" in n and "true>" in n)]
         if one:       # the whole step is one launch
             return one[0]["hbm_bytes_per_launch"], f"profiles/{os.path.basename(f)} [{stem}]: one launch per step"
-        two = [v for n, v in ks.items() if "ekv_attn_chunk_kernel" in n or "ekv_score_select_kernel" in n]
+        two = [v for n, v in ks.items() if "ekv_attn_chunk_kernel" in n or "ekv_attn_wide_kernel" in n or "ekv_score_select_kernel" in n]
         steps = [v["launches"] for n, v in ks.items() if "ekv_score_select_kernel" in n]
         if two and steps:
             # launches per step from the launch counts: the statistics pass and the exact pass of the two-pass scheme carry the same

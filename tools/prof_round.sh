@@ -3,7 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md: they do not fit one pass; never combined with a trace)
 # for the decode bench and for each strided-prefill shape.  Raw outputs -> gpurun_out/prof_$TAG; tools/summarize_prof.py
 # condenses them into profiles/${TAG}_*.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -25,7 +25,7 @@ for cfg in "c2 4096 8 24" "s64 4096 64 12" "c4 9994 96 8"; do
   run_pmc chunk_$1_fetch FETCH_SIZE python $R/tools/bench_chunk.py $2 $3 $4
   run_pmc chunk_$1_write WRITE_SIZE python $R/tools/bench_chunk.py $2 $3 $4
 done
-bash $R/tools/sq_counters.sh > $OUT/sq_counters.txt 2>&1
+timeout 600 bash $R/tools/sq_counters.sh > $OUT/sq_counters.txt 2>&1
 cd $R
-python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 ls $OUT
