@@ -154,7 +154,7 @@ class BudgetedKVCache:
         k = k.to(torch.float16).contiguous()
         v = v.to(torch.float16).contiguous()
         rep = self.bank.n_q_heads // self.bank.n_kv_heads
-        wide_two_pass = not self.streaming and rep in (1, 2, 4) and self.bank.head_dim in (64, 128)   # (ekv_chunk_wide's rule)
+        wide_two_pass = not self.streaming and rep in (1, 2, 4, 8, 16) and self.bank.head_dim in (64, 128)   # (ekv_chunk_wide's rule)
         if self.score_prefix and n > PREFIX_BLOCK and not wide_two_pass:
             # keep_attention: the dense prefix must also feed the score rows (easykv/easykv.py:173-186).  ONE launch per layer
             # when the step can run as a statistics pass + an exact pass with in-kernel column sums (below: the query blocks are

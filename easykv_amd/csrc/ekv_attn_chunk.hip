@@ -54,7 +54,7 @@ bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, 
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(rep, q_len, &qb_rows, &n_qblocks, &qpw);
   if (qpw < 2) return false;                                  // <= 32 rows: HBM-bound shapes, the small-tile kernels
-  if (two_pass) return rep == 1 || rep == 2 || rep == 4;      // the exact pass folds the rep query heads inside a register quad
+  if (two_pass) return rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // the exact pass folds the rep query heads in registers
   return !wants_logits;
 }
 

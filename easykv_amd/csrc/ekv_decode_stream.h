@@ -11,11 +11,11 @@
 
 constexpr int kU = 8;   // rows in flight per lane group (K and V each)
 
-template <int D, int NW = 4>
+template <int D, int NW = 4, int KU = kU>
 struct EkvDecodeGeom {
   static constexpr int LPR = D / 8;   // lanes per row
   static constexpr int G = 64 / LPR;  // rows per wave-load
-  static constexpr int RW = G * kU;   // rows per wave per iteration
+  static constexpr int RW = G * KU;   // rows per wave per iteration
   static constexpr int NP = NW;       // partials per workgroup = waves (lane groups are combined in-wave)
   static constexpr int PS = D + 2;    // (m, l, o[D])
 };
@@ -39,15 +39,18 @@ struct EkvDecodeGeom {
 struct EkvNoop {
   __device__ __forceinline__ void operator()() const {}
 };
-template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4, bool PHYS = false, typename MaskReady = EkvNoop>
+// KU = rows in flight per lane group (K and V each): 8 (122 VGPRs in the fused kernel = four workgroups per CU).  16 is
+// supported for plain keys in logical order and was tried in the split kernel (ekv_attn_decode.inc): no gain.
+template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4, bool PHYS = false, int KU = kU, typename MaskReady = EkvNoop>
 __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
                                                   int logit_stride, int t0, int t1_in, int ll, int h, size_t head_row,
                                                   float (&m)[REP], float (&l)[REP], float (&o)[REP][8],
                                                   const uint8_t* s_dead = nullptr, MaskReady mask_ready = MaskReady()) {
-  using Gm = EkvDecodeGeom<D, NW>;
+  using Gm = EkvDecodeGeom<D, NW, KU>;
   constexpr int LPR = Gm::LPR, RW = Gm::RW;
   constexpr int kNW = NW;
   static_assert(!(PHYS && (ROPE || SLOT_LDS)), "physical-order streaming: plain keys, global slot map");
+  static_assert(KU % 8 == 0 && (!PHYS || KU == 8) && KU <= 16, "8 or 16 rows per lane group; the dead-row mask is one byte per 8 rows");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int t_new = a.n_slots - 1;  // the appended position
@@ -152,27 +155,35 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     return;
   }
 
-  static_assert(kU == 8, "index prefetch assumes 8 rows per lane group");
   if (PHYS) t1 = a.phys_extent;   // loop bound: physical rows [0, E); which of them count is s_dead's business
   const int last_slot = PHYS ? 0 : s_slot[t1 - 1 - slot_base];
-  const int idx_cap = (a.cap - 8) & ~7;   // prefetches past t1 stay inside the head's map row (values unused)
-  uint4 ia = {0, 0, 0, 0}, ib = {0, 0, 0, 0};   // !SLOT_LDS: slot indices of rows j0..j0+7 of the next iteration
+  const int idx_cap = (a.cap - KU) & ~7;   // prefetches past t1 stay inside the head's map row (values unused)
+  uint4 iv[KU / 4];                        // !SLOT_LDS: slot indices of rows j0..j0+KU-1 of the next iteration
+#pragma unroll
+  for (int i = 0; i < KU / 4; ++i) iv[i] = uint4{0, 0, 0, 0};
   if (!PHYS && !SLOT_LDS && t0 + wave * RW < t1) {
-    const uint4* ip = reinterpret_cast<const uint4*>(s_slot + min(t0 + wave * RW + grp * kU, idx_cap));
-    ia = ip[0];
-    ib = ip[1];
+    const uint4* ip = reinterpret_cast<const uint4*>(s_slot + min(t0 + wave * RW + grp * KU, idx_cap));
+#pragma unroll
+    for (int i = 0; i < KU / 4; ++i) iv[i] = ip[i];
   }
   auto iteration = [&](const int base, auto&& after_issue) {
-    uint4 kr[kU], vr[kU];
-    const int j0 = base + grp * kU;
-    const int cur[8] = {(int)ia.x, (int)ia.y, (int)ia.z, (int)ia.w, (int)ib.x, (int)ib.y, (int)ib.z, (int)ib.w};
+    uint4 kr[KU], vr[KU];
+    const int j0 = base + grp * KU;
+    int cur[KU];
+#pragma unroll
+    for (int i = 0; i < KU / 4; ++i) {
+      cur[4 * i] = (int)iv[i].x;
+      cur[4 * i + 1] = (int)iv[i].y;
+      cur[4 * i + 2] = (int)iv[i].z;
+      cur[4 * i + 3] = (int)iv[i].w;
+    }
     if (!PHYS && !SLOT_LDS && base + kNW * RW < t1) {     // next iteration's indices (the map row has >= t_pad entries)
       const uint4* ip = reinterpret_cast<const uint4*>(s_slot + min(j0 + kNW * RW, idx_cap));
-      ia = ip[0];
-      ib = ip[1];
+#pragma unroll
+      for (int i = 0; i < KU / 4; ++i) iv[i] = ip[i];
     }
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
+    for (int u = 0; u < KU; ++u) {
       const int j = j0 + u;
       const int jj = j < t1 ? j : t1 - 1;
       const int row = PHYS ? jj : (SLOT_LDS ? s_slot[jj - t0] : (j < t1 ? cur[u] : last_slot));
@@ -188,13 +199,13 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     const unsigned dead8 = PHYS ? s_dead[j0 >> 3] : 0u;
     if (PHYS && dead8 != 0u) {   // rare: a dead row may hold anything (0 * inf = NaN in the PV accumulation)
 #pragma unroll
-      for (int u = 0; u < kU; ++u)
+      for (int u = 0; u < KU; ++u)
         if ((dead8 >> u) & 1u) vr[u] = uint4{0, 0, 0, 0};
     }
-    float sall[ROPE ? REP : 1][kU];   // ROPE: every row is rotated once, then dotted with all REP queries
+    float sall[ROPE ? REP : 1][KU];   // ROPE: every row is rotated once, then dotted with all REP queries
     if (ROPE) {
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
+      for (int u = 0; u < KU; ++u) {
         float kp[8];
         rope_key(kr[u], min(j0 + u, t1 - 1), kp);
 #pragma unroll
@@ -209,9 +220,9 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     }
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
-      float s[kU];
+      float s[KU];
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
+      for (int u = 0; u < KU; ++u) {
         if (ROPE) {
           s[u] = sall[r][u];
         } else {
@@ -222,19 +233,19 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
       }
       // export the raw logits: lane `sub` of the group owns row j0+sub -> 8 consecutive floats per group
       // (D = 32 has only 4 lanes per row: each lane then owns rows sub and sub + 4)
-      constexpr int NST = (kU + LPR - 1) / LPR;
+      constexpr int NST = (KU + LPR - 1) / LPR;
 #pragma unroll
       for (int st = 0; st < NST; ++st) {
         const int mu = sub + st * LPR;
         float mine = s[0];
 #pragma unroll
-        for (int u = 1; u < kU; ++u) mine = (mu == u) ? s[u] : mine;
-        if (logit_out != nullptr && mu < kU && (PHYS ? !((dead8 >> mu) & 1u) : (j0 + mu < t1)))
+        for (int u = 1; u < KU; ++u) mine = (mu == u) ? s[u] : mine;
+        if (logit_out != nullptr && mu < KU && (PHYS ? !((dead8 >> mu) & 1u) : (j0 + mu < t1)))
           logit_out[(size_t)r * logit_stride + j0 + mu] = mine;
       }
       float mx = s[0];
 #pragma unroll
-      for (int u = 1; u < kU; ++u) mx = fmaxf(mx, s[u]);
+      for (int u = 1; u < KU; ++u) mx = fmaxf(mx, s[u]);
       const float mn = fmaxf(m[r], mx);
       if (mn == EKV_NEG_INF) continue;  // whole group out of range
       const float alpha = exp2f((m[r] - mn) * EKV_LOG2E);
@@ -242,7 +253,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[r][i] *= alpha;
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
+      for (int u = 0; u < KU; ++u) {
         const float p = exp2f((s[u] - mn) * EKV_LOG2E);
         l[r] += p;
         ekv_axpy8(p, vr[u], o[r]);

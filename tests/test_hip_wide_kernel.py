@@ -45,6 +45,9 @@ SHAPES = [
     (64, 8, 2, 30, 100, 2),
     (64, 4, 2, 64, 0, 0),
     (64, 2, 2, 45, 40, 0),
+    (128, 16, 2, 12, 150, 0),     # GQA x8 (Llama-3-70B grouping): a query's heads span both half-waves, 96 rows
+    (128, 16, 2, 40, 60, 0),      # GQA x8 over three query blocks
+    (64, 16, 1, 6, 100, 2),       # GQA x16, 96 rows, splits
 ]
 
 
