@@ -127,3 +127,24 @@ def test_hipgraph_decode_step_equals_eager(mode, cfg, prompt):
     assert o0 == o1 and l0 == l1 and t0 == t1
     assert torch.equal(s0, s1) and torch.equal(sc0, sc1)
     assert torch.equal(kv0[0], kv1[0]) and torch.equal(kv0[1], kv1[1])
+
+
+@pytest.mark.parametrize("task, extra, expect", [
+    ("decoding", ["--budgets", "40", "--max-new-tokens", "50"], ["EasyKV-roco(budget 40)"]),
+    ("summarization", ["--max-new-tokens", "6"], ["KV cache budget ratio", "EasyKV-roco(50.00%)"]),
+    ("passkey", ["--filler", "30"], ["#Tokens of Prompt:", "KV cache budget ratio", "EasyKV-roco(50.00%)", "retrieved"]),
+    ("passkey_ntk", ["--filler", "30", "--ntk-length", "2000"], ["DynamicNTKRoPE max length reset to 2000", "EasyKV-roco(50.00%)"]),
+    ("ppl", ["--filler", "30", "--ntk-length", "2000"], ["Input token length:", "EasyKV-recency-50.00% PPL:", "EasyKV-roco-50.00% PPL:"]),
+])
+def test_example_runners(task, extra, expect):
+    """examples/run_task.py = the reference's runner scripts (test_decoding.py, test_summarization.py, test_passkey.py,
+    test_passkey_NTK.py, test_ppl.py) over this package: each task end to end on a tiny random-init HF Llama with synthetic ids."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_task.py"), task, "--random-init", "tiny"] + extra,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for line in expect:
+        assert line in r.stdout, (line, r.stdout[-1500:])
