@@ -171,7 +171,7 @@ def event_overhead_us(dev, reps=32):
     return v[len(v) // 2]
 
 
-def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
+def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="encoding", budget=0.5, streaming=False, shape=None):
     """Secondary figures (never `value`): the chunk phase of a strided prefill (SURVEY.md §8d Bench-P).  Default = BASELINE.json
     configs[1]: S=4096, stride 8, budget 0.5, kv_policy roco; also run at stride 64 / 96 and at the configs[3] shape
     (S=9994, stride 96).  The cache oscillates idx <-> idx+stride, every chunk step attends the retained slots with `stride`
@@ -179,10 +179,15 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
     from easykv_amd import KVBank, StepPlan, geometry
     L, Hq, D = args.layers, args.heads, args.head_dim
     H = args.kv_heads or Hq
-    bp, idx, r_idx = geometry("encoding", S, 0.5, stride)
+    if shape is not None:          # (layers, query heads, KV heads) of another BASELINE config
+        L, Hq, H = shape
+    bp, idx, r_idx = geometry(mode, S, budget, stride)
     g = torch.Generator(device=dev).manual_seed(4321)
     rnd = lambda h, n: torch.randn(L, h, n, D, generator=g, device=dev).half()
     bank = KVBank(L, Hq, H, D, cap=idx + stride, device=dev)
+    if streaming:                  # keys cached un-rotated, RoPE by slot index on every read (easykv/llama_patch.py:310-327)
+        from easykv_amd.api import rope_tables
+        bank.set_rope(*rope_tables(idx + stride + 64, D))
     bank.load_rows(rnd(H, idx), rnd(H, idx))          # state after the dense prefix and the fill-up chunks
     if not args.identity_layout:                      # steady state of the chunk phase: rows recycled in place for many steps
         bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=g, device=dev), dim=-1).int()
@@ -192,7 +197,7 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
     n_in = 2 * warm + n_chunks + 8
     qs_, ks_, vs_ = [rnd(Hq, stride) for _ in range(n_in)], [rnd(H, stride) for _ in range(n_in)], [rnd(H, stride) for _ in range(n_in)]
     plan = StepPlan(policy=args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco", phase="prefill", accumulate=True, evict=True,
-                    budget=bp, recent=int(bp * 0.1), sink=4, stride=stride, tova_head_mean=True)
+                    budget=bp, recent=int(bp * 0.1), sink=4, stride=stride, tova_head_mean=True, streaming=streaming)
     out = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
     ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
     # whole step as the library runs it (phases = 0: one launch when the scorer fuses into the attention kernel) ...
@@ -224,9 +229,10 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8):
     T = idx + stride
     n_state = {"roco": 3, "h2o_head": 1, "tova": 1}[plan.policy]
     by = algorithmic_bytes(H, Hq, D, T, stride, n_state)
-    traffic, traffic_src = prefill_pmc(S, stride, L, Hq, H, D, plan.policy)
+    traffic, traffic_src = (None, None) if (streaming or shape is not None) else prefill_pmc(S, stride, L, Hq, H, D, plan.policy)
     gbs = by["total"] * L / t_step / 1e9
-    return {"workload": f"bench-P chunk phase: S={S} stride={stride} budget=0.5 -> idx={idx}, T={T}, L={L} Hq={Hq} H={H} D={D} kv_policy={plan.policy}",
+    return {"workload": f"bench-P chunk phase: S={S} stride={stride} budget={budget:.4g} ({mode} geometry) -> idx={idx}, T={T}, L={L} Hq={Hq} H={H} D={D} "
+                        f"kv_policy={plan.policy}" + (", streaming=True (RoPE by slot index on every read)" if streaming else ""),
             "value": stride / t_step, "unit": "prompt tokens/s (chunk phase, attention/eviction path only)",
             "us_per_chunk_step": t_step * 1e6, "one_launch": one_launch,
             "as_two_launches_us": {"attn_kernel": t_attn * 1e6, "score_select": t_score * 1e6},
@@ -843,7 +849,10 @@ def main():
                                           traffic_over_algorithmic=live / sp["roofline"]["bytes_per_step"])
             line["strided_prefill_more"] = [strided_prefill(args, dev, S=4096, stride=64, n_chunks=24),
                                             strided_prefill(args, dev, S=4096, stride=96, n_chunks=16),
-                                            strided_prefill(args, dev, S=9994, stride=96, n_chunks=16)]
+                                            strided_prefill(args, dev, S=9994, stride=96, n_chunks=16),
+                                            # BASELINE configs[4]: Llama2-13B heads, ppl-mode geometry, streaming RoPE-on-read
+                                            strided_prefill(args, dev, S=10253, stride=96, n_chunks=8, warm=4, mode="ppl", budget=4096 / 10253,
+                                                            streaming=True, shape=(40, 40, 40))]
             if not args.no_live_pmc and (args.layers, Hq, H, D, args.policy) == (32, 32, 32, 128, "roco"):
                 # wide strides: a step is several launches (statistics pass, exact pass, scorer) — all of them measured in this run
                 for spm, sargs in ((line["strided_prefill_more"][0], ["4096", "64", "8"]), (line["strided_prefill_more"][2], ["9994", "96", "6"])):
