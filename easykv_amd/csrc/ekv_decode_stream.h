@@ -50,7 +50,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   constexpr int LPR = Gm::LPR, RW = Gm::RW;
   constexpr int kNW = NW;
   static_assert(!(PHYS && (ROPE || SLOT_LDS)), "physical-order streaming: plain keys, global slot map");
-  static_assert(KU % 8 == 0 && (!PHYS || KU == 8) && KU <= 16, "8 or 16 rows per lane group; the dead-row mask is one byte per 8 rows");
+  static_assert((KU == 4 || KU == 8 || KU == 16) && (!PHYS || KU <= 8), "4, 8 or 16 rows per lane group; the dead-row mask is one byte per 8 rows");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPR, grp = lane / LPR;
   const int t_new = a.n_slots - 1;  // the appended position
@@ -196,7 +196,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
     }
     after_issue();
     // PHYS: bit u of dead8 = row j0+u is free / being appended / past the extent (j0 is a multiple of 8: one mask byte)
-    const unsigned dead8 = PHYS ? s_dead[j0 >> 3] : 0u;
+    const unsigned dead8 = PHYS ? (KU == 4 ? ((unsigned)s_dead[j0 >> 3] >> (j0 & 4)) & 0xFu : (unsigned)s_dead[j0 >> 3]) : 0u;
     if (PHYS && dead8 != 0u) {   // rare: a dead row may hold anything (0 * inf = NaN in the PV accumulation)
 #pragma unroll
       for (int u = 0; u < KU; ++u)
