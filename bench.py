@@ -850,6 +850,8 @@ def main():
             line["strided_prefill_more"] = [strided_prefill(args, dev, S=4096, stride=64, n_chunks=24),
                                             strided_prefill(args, dev, S=4096, stride=96, n_chunks=16),
                                             strided_prefill(args, dev, S=9994, stride=96, n_chunks=16),
+                                            # BASELINE configs[2]: Mistral GQA (8 KV heads), stride 16, budget 0.3
+                                            strided_prefill(args, dev, S=4096, stride=16, n_chunks=24, budget=0.3, shape=(32, 32, 8)),
                                             # BASELINE configs[4]: Llama2-13B heads, ppl-mode geometry, streaming RoPE-on-read
                                             strided_prefill(args, dev, S=10253, stride=96, n_chunks=8, warm=4, mode="ppl", budget=4096 / 10253,
                                                             streaming=True, shape=(40, 40, 40))]

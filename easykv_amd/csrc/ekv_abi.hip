@@ -189,7 +189,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   w.n_qblocks = 1;
   int qpw = 1;
   if (st->q_len > 1) ekv_chunk_blocks(rep, st->q_len, &w.qb_rows, &w.n_qblocks, &qpw);
-  // key-range splits: aim for >= 1024 workgroups, never fewer than 256 positions per split
+  // key-range splits
   const int wg_unit = st->q_len == 1 ? 128 : 64;
   int n_split = st->n_split;
   w.fused_nw = ekv_decode_fused_nw(st->layer_count * bank->n_kv_heads);
@@ -197,21 +197,34 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
       ekv_decode_fused_supported(bank->head_dim, rep, T, w.t_pad, ekv_fused_logit_pad(bank, st, w.t_pad), st->n_evict, bank->cap, 8)) {
     n_split = 1;   // >= 1 head per CU: one 8-wave workgroup per head beats key-range splits + a second kernel (GQA shapes)
   }
-  if (n_split <= 0 && st->q_len > 1 && qpw <= 2 && w.n_qblocks == 1 && st->layer_count * bank->n_kv_heads >= 1024) {
-    // >= 4 heads per CU: unsplit heads fill the chip (measured at C2 / stride 16: no slower than 3 splits even with a separate
-    // scorer, because the fold moves into the kernel) and the scorer can then run as the tail of the attention kernel
-    n_split = 1;
-  }
-  if (n_split <= 0) {
+  const bool two_pass_plan = st->q_len > 1 && ekv_chunk_two_pass(rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass);
+  const bool wide_plan = st->q_len > 1 && ekv_chunk_wide(bank->head_dim, rep, st->q_len, st->rope_on_read != 0, two_pass_plan,
+                                                        !two_pass_plan && scored && st->accumulate != 0);
+  if (n_split <= 0 && st->q_len > 1) {
+    // Chunk steps (two or three workgroups per CU): a split costs a partial per query row and split, a fold in the scorer and a
+    // shorter stream per workgroup, so the grid is filled to the 256..512 workgroups that are resident at a time — not to 1024:
+    // the fewest splits (powers of two, <= 8) that give every CU a workgroup, doubled once more if a split then still streams
+    // >= 1024 rows.  Measured (us per step, MI355X, round 3, scratch/split_sweep.py; this rule / what the 1024- or 3072-target picked):
+    //   wide kernel, 8 KV heads x 1 layer, 64 rows, T = 1248 / 2176 / 5098:  46.7 / 54.7 / 76.2   (50.0 / 61.4 / 84.8)
+    //   wide kernel, 32 heads x 1 layer, 96 rows:                            63.9 / 76.6 / 110.5  (69.6 / 91.6 / 155.9)
+    //   wide kernel, 128 (head, layer) pairs, 96 rows:                       97.8 / 110.8 / 182.0 (108.6 / 132.5 / 208.6)
+    //   wide kernel, 256 pairs (configs[2]: 8 KV heads x 32 layers):         87.2 / 131.7 / 239.7 (116.3 / 154.1 / 265.4)
+    //   RoPE-on-read (16x16 kernel), 32 heads x 1 layer, 96 rows, T = 2176 / 4205:  127.4 / 166.4  (152.3 / 228.7)
+    //   16x16 kernel, GQA x4 stride 8 (32 rows), 64 pairs, T = 2176 / 4205:  57.9 / 87.9   (72.9 / 110.0);  256 pairs: 109.4 / 190.4 (126.8 / 207.5)
+    //   16x16 kernel, stride 16 MHA, 256 pairs:                              93.3 / 155.6  (99.4 / 173.0)
     const int wgs = st->layer_count * bank->n_kv_heads * w.n_qblocks;
-    // decode: >= 1024 workgroups (4 per CU, one round).  chunk kernels hold 3 (QPW=1) or 2 workgroups per CU: a grid of
-    // exactly 1024 would leave a quarter of it to a second, nearly empty round, so QPW=1 aims at 4 full rounds (3072).
-    const int target = (st->q_len > 1 && qpw == 1) ? 3072 : 1024;
-    n_split = std::max(1, std::min((target + wgs - 1) / wgs, st->q_len == 1 ? (T + 127) / 128 : (T + 255) / 256));
+    n_split = 1;
+    while (wgs * n_split < 256 && n_split < 8) n_split *= 2;
+    if (wgs * n_split < 512 && n_split < 8 && T / (2 * n_split) >= 1024) n_split *= 2;
+    n_split = std::max(1, std::min(n_split, (T + 255) / 256));
+  }
+  if (n_split <= 0) {      // decode: >= 1024 workgroups (4 per CU, one round), never fewer than 128 positions per split
+    const int wgs = st->layer_count * bank->n_kv_heads;
+    n_split = std::max(1, std::min((1024 + wgs - 1) / wgs, (T + 127) / 128));
     // decode launches of a few heads (one layer per call): the launch is latency-bound and ends with the fold of the key-range
     // partials, whose loads go out in batches of 8 — up to 8 splits are ONE round trip.  Measured at 32 heads, T = 2049
     // (us per layer, attention + in-kernel fold): 5 splits 15.4, 6..8 13.7, 10..17 14.6..14.7.
-    if (st->q_len == 1 && n_split > 8 && wgs * 8 >= 256) n_split = 8;
+    if (n_split > 8 && wgs * 8 >= 256) n_split = 8;
   }
   if (st->q_len > 1) {
     // the chunk kernel caches the slot indices of its key range in LDS next to its tiles and query block: bound the range
@@ -222,9 +235,8 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   int rows = (int)ekv_align((size_t)(T + n_split - 1) / n_split, wg_unit);
   w.rows_per_split = rows;
   w.n_split = (T + rows - 1) / rows;
-  w.two_pass = ekv_chunk_two_pass(rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass) ? 1 : 0;
-  w.wide = ekv_chunk_wide(bank->head_dim, rep, st->q_len, st->rope_on_read != 0, w.two_pass != 0,
-                          !w.two_pass && scored && st->accumulate != 0) ? 1 : 0;
+  w.two_pass = two_pass_plan ? 1 : 0;
+  w.wide = wide_plan ? 1 : 0;
   // partials per query row: one per split (decode, wide chunk kernel) or one per split and key half (16x16 chunk kernel)
   w.n_partials = (st->q_len == 1 || w.wide) ? w.n_split : 2 * w.n_split;
   const size_t rowsq = (size_t)st->layer_count * bank->n_q_heads * st->q_len;
