@@ -16,7 +16,7 @@ POLICY_CODES = {"full": POLICY_NONE, "h2o_head": POLICY_H2O_HEAD, "roco": POLICY
                 "recency": POLICY_RANGE, "random": POLICY_RANGE}
 
 EXPORTS = ("ekv_abi_version", "ekv_strerror", "ekv_workspace_bytes", "ekv_step_plan", "ekv_bank_reset", "ekv_state_init",
-           "ekv_step_attend", "ekv_gather_ordered", "ekv_scatter_rows", "ekv_compact_inplace", "ekv_step_check")
+           "ekv_step_attend", "ekv_gather_ordered", "ekv_scatter_rows", "ekv_compact_inplace", "ekv_step_check", "ekv_step_info")
 
 
 class Bank(C.Structure):
@@ -66,9 +66,10 @@ def load():
     lib.ekv_scatter_rows.argtypes = [C.POINTER(Bank), i32, i32, i32, i32, vp, vp, vp]
     lib.ekv_compact_inplace.argtypes = [C.POINTER(Bank), i32, i32, i32, i32, vp, vp]
     lib.ekv_step_check.argtypes = [C.POINTER(Bank), C.POINTER(Step)]
+    lib.ekv_step_info.argtypes = [C.POINTER(Bank), C.POINTER(Step), C.POINTER(C.c_int32), C.c_int32]
     for name in EXPORTS[3:]:
         getattr(lib, name).restype = C.c_int
-    if lib.ekv_abi_version() != 4:
+    if lib.ekv_abi_version() != 5:
         raise EkvError("ABI version mismatch")
     _lib = lib
     return lib

@@ -139,6 +139,13 @@ class BudgetedKVCache:
         finally:
             _ACTIVE.reset(tok)
 
+    def _prefix_in_one_step(self, plan, n, layer_idx) -> bool:
+        key = (plan.policy, plan.accumulate, plan.two_pass, type(self.bank).default_two_pass, self.streaming, n)
+        if getattr(self, "_prefix_rule", (None, None))[0] != key:
+            info = self.bank.step_info(plan, n, layer_idx, 1)
+            self._prefix_rule = (key, bool(info["two_pass"] and info["wide"]))
+        return self._prefix_rule[1]
+
     def attend(self, layer_idx: int, q, k, v):
         """One layer of one forward: append + attention + score + select + compaction, all on device.
         ``layer_idx`` is the layer's index in the MODEL; it must lie in this cache's block."""
@@ -153,14 +160,12 @@ class BudgetedKVCache:
         q = q.to(torch.float16).contiguous()
         k = k.to(torch.float16).contiguous()
         v = v.to(torch.float16).contiguous()
-        rep = self.bank.n_q_heads // self.bank.n_kv_heads
-        wide_two_pass = not self.streaming and rep in (1, 2, 4, 8, 16) and self.bank.head_dim in (64, 128)   # (ekv_chunk_wide's rule)
-        if self.score_prefix and n > PREFIX_BLOCK and not wide_two_pass:
-            # keep_attention: the dense prefix must also feed the score rows (easykv/easykv.py:173-186).  ONE launch per layer
-            # when the step can run as a statistics pass + an exact pass with in-kernel column sums (below: the query blocks are
-            # walked inside the launch by the wide-block kernel and nothing of size r x r exists anywhere); the other kernels
-            # (RoPE-on-read, GQA factors above 4, head_dim 32) export logits or one column-sum row per query block to a workspace,
-            # so there the prefix is cut into query blocks here
+        if self.score_prefix and n > PREFIX_BLOCK and not self._prefix_in_one_step(plan, n, layer_idx):
+            # keep_attention: the dense prefix must also feed the score rows (easykv/easykv.py:173-186).  ONE launch pair per layer
+            # when the LIBRARY says the step runs as the two-pass scheme on the wide-block kernel (ekv_step_info: the query blocks
+            # are walked inside the launch and nothing of size r x r exists anywhere); every other dispatch (RoPE-on-read,
+            # head_dim 32, odd GQA factors, EKV_NO_WIDE, a forced one-pass scheme) exports logits or one column-sum row per query
+            # block to a workspace, so there the prefix is cut into query blocks here
             outs = []
             for i0 in range(0, n, PREFIX_BLOCK):
                 o, _ = self.bank.attend(plan, q[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), k[:, :, i0:i0 + PREFIX_BLOCK].contiguous(),

@@ -332,6 +332,18 @@ int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, in
   return EKV_OK;
 }
 
+int ekv_step_info(const ekv_bank* bank, const ekv_step* st, int32_t* info, int32_t n_info) {
+  if (int e = check_bank(bank)) return e;
+  if (!st || !info || n_info < 1) return EKV_E_ARG;
+  int32_t n_split = 0, fused = 0;
+  if (int e = ekv_step_plan(bank, st, &n_split, &fused)) return e;
+  const EkvWs ws = ekv_plan_workspace(bank, st, nullptr);
+  const int32_t v[EKV_STEP_INFO_N] = {n_split, fused, ws.two_pass, ws.wide, ws.n_qblocks, ws.qb_rows, ws.n_col_parts, ws.fold_in_kernel};
+  for (int i = 0; i < n_info && i < EKV_STEP_INFO_N; ++i) info[i] = v[i];
+  for (int i = EKV_STEP_INFO_N; i < n_info; ++i) info[i] = 0;
+  return EKV_OK;
+}
+
 int ekv_bank_reset(const ekv_bank* bank, void* stream) {
   if (int e = check_bank(bank)) return e;
   drop_stale_error();
@@ -505,7 +517,9 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // Whole chunk step in ONE launch: unsplit heads (the kernel folds its own output), one-pass logits, a scored policy, and the
   // scorer's LDS rows fit next to two workgroups per CU.  The scorer of a head then runs as the tail of the workgroup that
   // streamed it and overlaps the K/V stream of the workgroups still running (tova_head_mean needs all heads of a layer first).
-  const bool fuse_chunk = n > 1 && ph == 0 && ws.fold_in_kernel && !ws.two_pass && scored && ws.n_qblocks == 1 &&
+  // (not on the wide-block kernel: it has no scorer tail — an unsplit scored step of 33..64 rows that exports no logits, i.e. the
+  //  first strided chunk of an encoding-mode prefill, runs as wide attention + scorer launch)
+  const bool fuse_chunk = n > 1 && ph == 0 && ws.fold_in_kernel && !ws.two_pass && !ws.wide && scored && ws.n_qblocks == 1 &&
                           rep * n <= 64 && !(st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) &&
                           ekv_score_lds_bytes_nt256(sa) <= 64 * 1024 && st->n_split != -1;
   if (fuse_chunk) sa.skip_fold = 1;

@@ -157,7 +157,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
 
   if (PHYS) t1 = a.phys_extent;   // loop bound: physical rows [0, E); which of them count is s_dead's business
   const int last_slot = PHYS ? 0 : s_slot[t1 - 1 - slot_base];
-  const int idx_cap = (a.cap - KU) & ~7;   // prefetches past t1 stay inside the head's map row (values unused)
+  const int idx_cap = (a.cap - KU) & ~(KU - 1);   // prefetches past t1 stay inside the head's map row (values unused); a multiple of KU like j0
   uint4 iv[KU / 4];                        // !SLOT_LDS: slot indices of rows j0..j0+KU-1 of the next iteration
 #pragma unroll
   for (int i = 0; i < KU / 4; ++i) iv[i] = uint4{0, 0, 0, 0};

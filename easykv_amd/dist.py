@@ -9,7 +9,9 @@ same code runs on ``gloo`` for the CPU tests.
 from __future__ import annotations
 
 import os
+import collections
 import time
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -118,12 +120,12 @@ def broadcast_object(obj, src: int):
     return box[0]
 
 
-_STAGES = []     # every PipelineStage of this process (drain_stages)
+_STAGES = weakref.WeakSet()     # the live PipelineStages of this process (drain_stages); a stage dies with its model
 
 
 def drain_stages():
     """Wait for every stage output this process has posted but whose transfer has not completed (end of a generate)."""
-    for st in _STAGES:
+    for st in list(_STAGES):
         st.drain()
 
 
@@ -146,9 +148,10 @@ class PipelineStage:
         self.depth = max(1, depth)
         self._posted = []          # (request, buffer kept alive) of stage outputs in flight, oldest first
         self.n_sent = 0
-        self.run_ahead = []        # per send: outputs still in flight right after posting (0 = the successor keeps up)
-        self.t_recv, self.t_send = [], []      # host clock (time.time) when forward i's input had arrived / its output was posted
-        _STAGES.append(self)
+        # evidence for the tests / bench, bounded (a long-running process must not grow by an entry per forward):
+        self.run_ahead = collections.deque(maxlen=4096)   # per send: outputs still in flight right after posting (0 = the successor keeps up)
+        self.t_recv, self.t_send = collections.deque(maxlen=4096), collections.deque(maxlen=4096)   # host clock when forward i's input had arrived / its output was posted
+        _STAGES.add(self)
 
     @property
     def first(self) -> bool:

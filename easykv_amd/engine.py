@@ -198,6 +198,15 @@ class KVBank:
         check(self.lib.ekv_step_plan(C.byref(self._bank), C.byref(st), C.byref(ns), C.byref(fu)), "ekv_step_plan")
         return ns.value, bool(fu.value)
 
+    def step_info(self, plan: StepPlan, q_len, layer_begin=0, layer_count=None, phases=0) -> dict:
+        """The library's dispatch decisions for this step (ekv_step_info): n_split, fused, two_pass, wide, n_qblocks, ..."""
+        st = self.make_step(plan, q_len, layer_begin, self.n_layers - layer_begin if layer_count is None else layer_count)
+        st.phases = phases
+        info = (C.c_int32 * 8)()
+        check(self.lib.ekv_step_info(C.byref(self._bank), C.byref(st), info, 8), "ekv_step_info")
+        keys = ("n_split", "fused", "two_pass", "wide", "n_qblocks", "qb_rows", "n_col_parts", "fold_in_kernel")
+        return dict(zip(keys, (int(x) for x in info)))
+
     def join(self):
         """Make the current stream wait for every scorer still running on a side stream."""
         cur = torch.cuda.current_stream(self.device)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define EKV_ABI_VERSION 4
+#define EKV_ABI_VERSION 5
 
 /* kv_policy strings of the reference -> codes (easykv/easykv.py:288-300, :310-362) */
 enum {
@@ -126,6 +126,15 @@ size_t ekv_workspace_bytes(const ekv_bank *bank, const ekv_step *step);
  * step is ONE launch (the fused decode kernel, the logits-in-LDS chunk kernel, or a chunk step whose scorer runs as the tail
  * of its attention kernel), 0 when it is an attention launch (two for the two-pass chunk scheme) + fold / scorer launches. */
 int ekv_step_plan(const ekv_bank *bank, const ekv_step *step, int32_t *n_split, int32_t *fused);
+
+/* The dispatch decisions behind ekv_step_plan, for host code that must shape its calls after them instead of mirroring the rules
+ * (ABI 5): info[0 .. n_info) <- { n_split, fused, two_pass (1 = statistics + column-sum scheme, no logits in HBM), wide (1 = the
+ * 32x32x16 wide-block kernel, which walks all query blocks of a head inside one launch), n_qblocks, qb_rows, n_col_parts,
+ * fold_in_kernel }; entries beyond EKV_STEP_INFO_N are zeroed.  The reference has no counterpart (its keep_attention prefix
+ * materialises the r x r map, easykv/easykv.py:396-405); easykv_amd.api uses it to decide whether a scored prefix goes down as
+ * one step or in query blocks. */
+#define EKV_STEP_INFO_N 8
+int ekv_step_info(const ekv_bank *bank, const ekv_step *step, int32_t *info, int32_t n_info);
 
 /* slot_of_pos <- identity for the whole bank */
 int ekv_bank_reset(const ekv_bank *bank, void *stream);

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-OUT_TOL = 1e-3
+OUT_TOL = 1e-3   # north_star: within 1e-3 on fp16 outputs — flat absolute bound, rtol = 0
 
 
 class _ProbeLog:
@@ -34,7 +34,22 @@ class _ProbeLog:
         self.unstable.append(bad)
 
 
-def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaForCausalLM", min_stable=0.9):
+def _report_stable(what, n_stable, n_dec, frac, floor):
+    """The achieved fraction of (layer, head, eviction) decisions that were BOUND to the oracle's: printed (pytest -s / -rA) and
+    appended to gpurun_out/stable_fractions.txt so a round's evidence run records it."""
+    import os
+    line = f"[stable-fraction] {what}: {n_stable}/{n_dec} = {frac:.4f} (floor {floor})"
+    print(line)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "stable_fractions.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaForCausalLM", min_stable=0.95):
     import easykv_amd
     from oracle import easykv_oracle as O
     from oracle.fake_model import FakeAttnModel, make_streams
@@ -79,7 +94,10 @@ def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaFo
         n_stable += int((alive & ok).sum())
         assert bool(same[alive & ok].all()), f"eviction {step}: stable decisions differ"
         alive &= ok & same
-    assert n_dec > 0 and n_stable >= min_stable * n_dec, (n_stable, n_dec)
+    frac = float(n_stable) / max(n_dec, 1)
+    _report_stable(f"{mode} stride={stride} L={n_layers} Hq={hq} H={h} S={length} {cfg.get('kv_policy')}"
+                   f"{' streaming' if cfg.get('streaming') else ''}{' keep_attention' if cfg.get('keep_attention') else ''}", n_stable, n_dec, frac, min_stable)
+    assert n_dec > 0 and frac >= min_stable, (n_stable, n_dec, frac, min_stable)
 
     # attention outputs: every forward until the first divergence of any head is comparable; the dense prefix and the
     # first chunk always are
@@ -87,8 +105,8 @@ def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaFo
     assert len(model.outputs_log) == len(ref_model.outputs_log)
     for f in range(min(first_div, len(model.outputs_log))):
         a, b = model.outputs_log[f], ref_model.outputs_log[f]
-        assert torch.allclose(a, b, rtol=OUT_TOL / 2, atol=OUT_TOL), (f, float((a - b).abs().max()))
-    return res, tr, float(n_stable) / n_dec
+        assert torch.allclose(a, b, rtol=0, atol=OUT_TOL), (f, float((a - b).abs().max()))
+    return res, tr, frac
 
 
 def test_config2_mistral_gqa_stride16_keep_attention_full_geometry():

@@ -14,7 +14,7 @@ import torch
 from tests.golden_util import golden_names, load_golden, split_ids, split_outputs
 
 pytestmark = pytest.mark.gpu
-OUT_TOL = 1e-3   # north_star: within 1e-3 on fp16 outputs (outputs are fp16: half-ulp at |o| in [1,2) is 4.9e-4)
+OUT_TOL = 1e-3   # north_star: within 1e-3 on fp16 outputs — flat absolute bound, rtol = 0
 
 
 def _cases():
@@ -56,7 +56,7 @@ def test_generate_matches_reference(name, chunk_scheme):
     assert len(model.outputs_log) == len(ref_out)
     for f, (a, b) in enumerate(zip(model.outputs_log, ref_out)):
         assert a.shape == b.shape
-        assert torch.allclose(a, b, rtol=OUT_TOL / 2, atol=OUT_TOL), (f, float((a - b).abs().max()))
+        assert torch.allclose(a, b, rtol=0, atol=OUT_TOL), (f, float((a - b).abs().max()))
     # evictions
     ours = [np.sort(torch.stack(e).cpu().numpy(), axis=-1) for e in cache.evictions]
     ref_ph, ref_rg = split_ids(g), g["ranges"].tolist()
@@ -122,7 +122,7 @@ def test_eos_branch_matches_reference(name, eos_poll):
         assert np.array_equal(a, b), f"eviction ids differ at eviction {step}"
     ref_out = split_outputs(g)
     for f, (a, b) in enumerate(zip(model.outputs_log, ref_out)):
-        assert a.shape == b.shape and torch.allclose(a, b, rtol=OUT_TOL / 2, atol=OUT_TOL), (f, float((a - b).abs().max()))
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=0, atol=OUT_TOL), (f, float((a - b).abs().max()))
     assert cache.host_syncs <= math.ceil(cache.tokens_sampled / poll) + 1
     if poll == 1:      # nothing ran past the EOS: forwards, evictions and the cache handed back are the reference's
         assert len(model.outputs_log) == len(ref_out) == m["n_forwards"]
@@ -138,3 +138,47 @@ def test_eos_branch_matches_reference(name, eos_poll):
         assert cache.get_seq_length() == expect
     else:
         assert cache.tokens_sampled <= min(m["config"]["max_new_tokens"], (n_tokens + poll - 1) // poll * poll)
+
+
+def test_sampler_on_the_device_matches_reference_fixture():
+    """VERDICT r3 missing #5: the product runs ``api.logits_adapter`` on the GPU (api.generate), where ``torch.sort``'s tie order and
+    ``cumsum``'s summation order are a different implementation from the CPU ops the fixture was produced with
+    (oracle/gen_sampler_golden.py imports the reference's logits_adapter, easykv/easykv.py:115-134).  The fixture holds exact ties at
+    the nucleus boundary (``ties_v16``) and an all-equal row (``flat_v33``).  Bar on the device: the SAME support (which tokens
+    survive the nucleus cut — a tie broken differently would change it) whenever the cut is not inside a group of exactly tied
+    probabilities, probabilities within 2e-6 of the reference's, rows summing to 1; and the greedy configuration
+    (temperature 1e-6) picks the reference's token."""
+    import os
+    import numpy as np
+    from easykv_amd.api import logits_adapter
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(root, "tests", "golden", "sampler", "logits_adapter.npz"))
+    keys = sorted({k.rsplit("|", 1)[0] for k in z.files})
+    assert len(keys) == 45
+    n_support = 0
+    for key in keys:
+        name, temperature, top_p = key.split("|")
+        logits = torch.from_numpy(z[key + "|logits"]).cuda()
+        final, raw = logits_adapter(logits, float(temperature), float(top_p))
+        ref_final, ref_raw = torch.from_numpy(z[key + "|final"]), torch.from_numpy(z[key + "|raw"])
+        final, raw = final.cpu(), raw.cpu().reshape(ref_raw.shape)
+        assert torch.allclose(raw, ref_raw, atol=2e-6, rtol=1e-5), key
+        assert torch.allclose(final.sum(-1), torch.ones(final.shape[:-1]), atol=1e-5), key
+        if float(temperature) < 1e-3:       # greedy: one-hot on the reference's token
+            assert torch.equal(final.argmax(-1), ref_final.argmax(-1)), key
+        # the nucleus cut lies inside a group of exactly tied probabilities <=> the reference keeps some but not all members of a
+        # group of equal softmax values: only then may the support differ (by WHICH tied tokens are kept, never by how many)
+        prob = torch.softmax(torch.from_numpy(z[key + "|logits"]) / float(temperature), dim=-1)
+        kept_ref, kept = ref_final > 0, final > 0
+        assert torch.equal(kept.sum(-1), kept_ref.sum(-1)), key
+        rows = prob.reshape(-1, prob.shape[-1])
+        for r, (pr, kr, kk) in enumerate(zip(rows, kept_ref.reshape(rows.shape), kept.reshape(rows.shape))):
+            cut_in_tie = any(bool(kr[pr == v].any()) and not bool(kr[pr == v].all()) for v in pr[kr].unique())
+            if not cut_in_tie:
+                assert torch.equal(kr, kk), (key, r)
+                n_support += 1
+                a, b = final.reshape(rows.shape)[r], ref_final.reshape(rows.shape)[r]
+                assert torch.allclose(a, b, atol=2e-6, rtol=1e-5), (key, r, float((a - b).abs().max()))
+            else:       # same multiset of kept probabilities
+                assert torch.allclose(torch.sort(pr[kk])[0], torch.sort(pr[kr])[0], atol=0, rtol=0), (key, r)
+    assert n_support >= 40

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+COL_RTOL = 5e-6
 
 
 def _scatter_bank(bank, k, v, t_prev, gen):
@@ -67,7 +68,7 @@ def test_unscored_step_matches_oracle(d, hq, h, n, t_prev, n_split):
     assert ids is None and bank.n_slots == [T] * L
     for l in range(L):
         o_ref, _, _ = _ref(q[l:l + 1], k[l:l + 1], v[l:l + 1], h)
-        assert torch.allclose(out[l].float().cpu(), o_ref, atol=1e-3, rtol=5e-4), float((out[l].float().cpu() - o_ref).abs().max())
+        assert torch.allclose(out[l].float().cpu(), o_ref, atol=1e-3, rtol=0), float((out[l].float().cpu() - o_ref).abs().max())
     # the new rows were appended: the ordered view equals the full K / V
     kk, vv = bank.ordered_kv()
     assert torch.equal(kk.cpu(), k) and torch.equal(vv.cpu(), v)
@@ -91,9 +92,11 @@ def test_scored_step_two_pass_matches_oracle(d, hq, h, n, t_prev, n_split):
                          q.cuda(), k[:, :, t_prev:].cuda().contiguous(), v[:, :, t_prev:].cuda().contiguous())
     for l in range(L):
         o_ref, s_ref, q_ref = _ref(q[l:l + 1], k[l:l + 1], v[l:l + 1], h)
-        assert torch.allclose(out[l].float().cpu(), o_ref, atol=1e-3, rtol=5e-4), float((out[l].float().cpu() - o_ref).abs().max())
-        assert torch.allclose(bank.score_sum[l, :, :T].cpu(), s_ref, rtol=2e-5, atol=1e-7)
-        assert torch.allclose(bank.score_sq[l, :, :T].cpu(), q_ref, rtol=2e-5, atol=1e-9)
+        assert torch.allclose(out[l].float().cpu(), o_ref, atol=1e-3, rtol=0), float((out[l].float().cpu() - o_ref).abs().max())
+        # (5e-6: a quarter of the +-2e-5 the stability probe perturbs the score rows by — the kernel's p = 2^(s*c - lse2) differs from
+        #  exp(s/sqrt(D) - max) / sum by ~1e-6 relative)
+        assert torch.allclose(bank.score_sum[l, :, :T].cpu(), s_ref, rtol=COL_RTOL, atol=1e-7), float(((bank.score_sum[l, :, :T].cpu() - s_ref).abs() / s_ref.abs().clamp_min(1e-6)).max())
+        assert torch.allclose(bank.score_sq[l, :, :T].cpu(), q_ref, rtol=COL_RTOL, atol=1e-9), float(((bank.score_sq[l, :, :T].cpu() - q_ref).abs() / q_ref.abs().clamp_min(1e-9)).max())
 
 
 def test_wide_and_small_tile_kernels_agree_on_eviction():
@@ -115,3 +118,31 @@ def test_wide_and_small_tile_kernels_agree_on_eviction():
         _, i = bank.attend(plan, q.cuda(), k[:, :, t_prev:].cuda().contiguous(), v[:, :, t_prev:].cuda().contiguous())
         ids.append(torch.sort(i.cpu(), dim=-1)[0])
     assert torch.equal(ids[0], ids[1])
+
+
+@pytest.mark.parametrize("d,hq,h,n,t_prev", [(128, 2, 2, 50, 77), (128, 8, 2, 16, 200), (64, 4, 4, 40, 90), (128, 4, 4, 33, 0)])
+def test_scored_unsplit_first_chunk_without_accumulate(d, hq, h, n, t_prev):
+    """the first strided chunk of an encoding-mode prefill — a SCORED policy, accumulate = False (T == idx),
+    nothing evicted, one split, one query block of 33..64 GQA-folded rows, no logits wanted — picked both the wide-block kernel
+    and the fused scorer tail of the 16x16 kernel and failed with EKV_E_LAUNCH.  It now runs as wide attention + scorer launch:
+    output against the oracle, score rows untouched, rows appended."""
+    from easykv_amd import KVBank, StepPlan
+    g = torch.Generator().manual_seed(3 * d + hq * 10 + n)
+    L, T = 2, t_prev + n
+    q = torch.randn(L, hq, n, d, generator=g).half()
+    k = torch.randn(L, h, T, d, generator=g).half()
+    v = torch.randn(L, h, T, d, generator=g).half()
+    bank = KVBank(L, hq, h, d, cap=T + 64)
+    _scatter_bank(bank, k, v, t_prev, g)
+    bank.state_init(T, 2, n)
+    before = [x.clone() for x in (bank.score_sum, bank.score_sq, bank.score_cnt)]
+    plan = StepPlan(policy="roco", phase="prefill", accumulate=False, evict=False, n_split=1, stride=n)
+    info = bank.step_info(plan, n)
+    assert info["n_split"] == 1 and info["wide"] == 1 and info["fused"] == 0
+    out, ids = bank.attend(plan, q.cuda(), k[:, :, t_prev:].cuda().contiguous(), v[:, :, t_prev:].cuda().contiguous())
+    assert ids is None and bank.n_slots == [T] * L
+    for l in range(L):
+        o_ref, _, _ = _ref(q[l:l + 1], k[l:l + 1], v[l:l + 1], h)
+        assert torch.allclose(out[l].float().cpu(), o_ref, atol=1e-3, rtol=0), float((out[l].float().cpu() - o_ref).abs().max())
+    for a, b in zip(before, (bank.score_sum, bank.score_sq, bank.score_cnt)):
+        assert torch.equal(a, b)

@@ -40,7 +40,8 @@ def test_abi_exports_every_declared_symbol():
     raw = ctypes.CDLL(_build.LIB)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.ekv_abi_version() == 4
+    assert lib.ekv_abi_version() == 5
+    assert lib.ekv_step_info(None, None, None, 0) == -1
     assert b"workspace" in lib.ekv_strerror(-3)
     # argument checking happens before any device access: callable without a GPU
     assert lib.ekv_workspace_bytes(None, None) == 0
