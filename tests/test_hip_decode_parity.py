@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.golden_util import golden_names, load_golden, split_ids, split_outputs
+from tests.golden_util import golden_names, load_golden, split_ids, split_outputs, out_close
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,7 @@ def test_decode_matches_reference_golden(name, n_split):
     ref_out = split_outputs(g)[1:]          # forward 0 is the prompt prefill
     assert len(outs) == len(ref_out)
     for a, b in zip(outs, ref_out):
-        assert torch.allclose(a, b, rtol=0, atol=OUT_TOL), float((a - b).abs().max())
+        assert out_close(a, b, OUT_TOL), float((a - b).abs().max())
     if g["meta"]["config"]["kv_policy"] == "recency":
         ref = [np.broadcast_to(np.array(r[0]), ids_log[0].shape) for r in g["ranges"]]
     else:
@@ -118,10 +118,10 @@ def test_eight_wave_fused_kernel_for_launches_with_one_or_two_heads_per_cu(hq, h
         o_f, i_f = banks["fused"].attend(StepPlan(**kw), q.cuda(), k.cuda(), v.cuda())
         o_s, i_s = banks["split"].attend(StepPlan(n_split=2, **kw), q.cuda(), k.cuda(), v.cuda())
         assert torch.equal(i_f, i_s), i
-        assert torch.allclose(o_f.float(), o_s.float(), atol=1e-3, rtol=0)
+        assert out_close(o_f.float(), o_s.float())
         for l in range(n_check):
             o_ref, ids_ref = O.layer_step(sts[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw), cos, sin)
-            assert torch.allclose(o_f[l].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+            assert out_close(o_f[l].float().cpu(), o_ref[0])
     assert torch.equal(banks["fused"].slot_of_pos, banks["split"].slot_of_pos)
     assert torch.allclose(banks["fused"].score_sum, banks["split"].score_sum, rtol=1e-6, atol=0)
 
@@ -176,10 +176,10 @@ def test_physical_order_stream_with_a_scattered_slot_map(hq, h, d, L, policy, ho
         o_s, i_s = banks["split"].attend(StepPlan(n_split=2, **kw), q.cuda(), k.cuda(), v.cuda())
         assert torch.equal(i_f, i_s), i
         assert torch.isfinite(o_f.float()).all()
-        assert torch.allclose(o_f.float(), o_s.float(), atol=1e-3, rtol=0)
+        assert out_close(o_f.float(), o_s.float())
         for l in range(n_check):
             o_ref, ids_ref = O.layer_step(sts[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw))
-            assert torch.allclose(o_f[l].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+            assert out_close(o_f[l].float().cpu(), o_ref[0])
     assert torch.equal(banks["fused"].slot_of_pos, banks["split"].slot_of_pos)
     if policy != "recency":
         assert torch.equal(banks["fused"].score_sum, banks["split"].score_sum)     # same summation order: bit-identical
@@ -212,7 +212,7 @@ def test_physical_order_stream_after_a_chunk_phase_leaves_holes():
         o_f, i_f = banks["fused"].attend(StepPlan(n_split=1, **dec), q.cuda(), k.cuda(), v.cuda())
         o_s, i_s = banks["split"].attend(StepPlan(n_split=2, **dec), q.cuda(), k.cuda(), v.cuda())
         assert torch.equal(i_f, i_s), i
-        assert torch.allclose(o_f.float(), o_s.float(), atol=1e-3, rtol=0)
+        assert out_close(o_f.float(), o_s.float())
     assert banks["fused"].extent == [idx + stride] * L
     assert torch.equal(banks["fused"].slot_of_pos, banks["split"].slot_of_pos)
     assert torch.equal(banks["fused"].score_sum, banks["split"].score_sum)

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.golden_util import out_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -84,7 +86,7 @@ def test_decode_full_size_bench_shape(policy):
                 o_ref, ids_ref = O.layer_step(states[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(),
                                               O.StepPlan(policy=policy, phase="decode", evict=True, budget=budget))
                 unstable = probe.last_unstable
-                assert torch.allclose(o_f[l].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+                assert out_close(o_f[l].float().cpu(), o_ref[0])
                 got = ids_f[l, :, 0].cpu().long()
                 same = got == ids_ref[:, 0]
                 n_dec += int(alive[l].sum())
@@ -130,7 +132,7 @@ def test_chunk_steps_full_size_c2_shape():
             kw = dict(policy="roco", phase="prefill", accumulate=t_now > idx, evict=t_now > idx, budget=bp, recent=recent, sink=sink, stride=s)
             out, ids = bank.attend(StepPlan(tova_head_mean=True, **kw), q.cuda(), k.cuda(), v.cuda())
             o_ref, ids_ref = O.layer_step(st, q.float(), k.float(), v.float(), O.StepPlan(tova_head_mean=True, **kw))
-            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+            assert out_close(out[0].float().cpu(), o_ref[0])
             if ids is not None:
                 unstable = probe.last_unstable
                 got = torch.sort(ids[0].cpu().long(), dim=-1)[0]
@@ -173,7 +175,7 @@ def test_c4_shape_stride96_and_long_decode_rows():
             kw = dict(policy="roco", phase="prefill", accumulate=True, evict=True, budget=bp, recent=recent, sink=sink, stride=s)
             out, ids = bank.attend(StepPlan(**kw), q.cuda(), k.cuda(), v.cuda())
             o_ref, ids_ref = O.layer_step(st, q.float(), k.float(), v.float(), O.StepPlan(**kw))
-            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+            assert out_close(out[0].float().cpu(), o_ref[0])
             got, ref = torch.sort(ids[0].cpu().long(), dim=-1)[0], torch.sort(ids_ref, dim=-1)[0]
             ok = ~probe.last_unstable
             assert bool((got == ref).all(dim=-1)[ok].all())
@@ -187,7 +189,7 @@ def test_c4_shape_stride96_and_long_decode_rows():
             kw = dict(policy="roco", phase="decode", accumulate=True, evict=True, budget=bp)
             out, ids = bank.attend(StepPlan(n_split=step % 2, **kw), q.cuda(), k.cuda(), v.cuda())
             o_ref, ids_ref = O.layer_step(st, q.float(), k.float(), v.float(), O.StepPlan(**kw))
-            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+            assert out_close(out[0].float().cpu(), o_ref[0])
             ok = ~probe.last_unstable
             assert bool((ids[0, :, 0].cpu().long() == ids_ref[:, 0])[ok].all())
             if not bool(ok.all()):
@@ -225,7 +227,7 @@ def test_wide_score_rows_beyond_one_cus_lds(policy, idx, s):
             kw = dict(policy=policy, phase="prefill", accumulate=True, evict=True, budget=bp, recent=recent, sink=sink, stride=s)
             out, ids = bank.attend(StepPlan(**kw), q.cuda(), k.cuda(), v.cuda())
             o_ref, ids_ref = O.layer_step(st, q.float(), k.float(), v.float(), O.StepPlan(**kw))
-            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+            assert out_close(out[0].float().cpu(), o_ref[0])
             got, ref = torch.sort(ids[0].cpu().long(), dim=-1)[0], torch.sort(ids_ref, dim=-1)[0]
             ok = ~probe.last_unstable
             assert bool((got == ref).all(dim=-1)[ok].all()), step
@@ -241,7 +243,7 @@ def test_wide_score_rows_beyond_one_cus_lds(policy, idx, s):
             kw = dict(policy=policy, phase="decode", accumulate=True, evict=True, budget=bp)
             out, ids = bank.attend(StepPlan(**kw), q.cuda(), k.cuda(), v.cuda())
             o_ref, ids_ref = O.layer_step(st, q.float(), k.float(), v.float(), O.StepPlan(**kw))
-            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+            assert out_close(out[0].float().cpu(), o_ref[0])
             ok = ~probe.last_unstable
             assert bool((ids[0, :, 0].cpu().long() == ids_ref[:, 0])[ok].all()), step
             checked += int(ok.sum())
@@ -279,7 +281,7 @@ def test_baseline_config0_geometry_decoding_budget200():
             out, ids = bank.attend(StepPlan(n_split=i % 3, **kw), qs[:, :, t:t + 1].cuda().contiguous(), ks[:, :, t:t + 1].cuda().contiguous(),
                                    vs[:, :, t:t + 1].cuda().contiguous())
             o_ref, ids_ref = O.layer_step(st, qs[:, :, t:t + 1].float(), ks[:, :, t:t + 1].float(), vs[:, :, t:t + 1].float(), O.StepPlan(**kw))
-            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0)
+            assert out_close(out[0].float().cpu(), o_ref[0])
             if evict:
                 got = ids[0, :, 0].cpu().long() - P
                 ok = ~probe.last_unstable

@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.golden_util import out_close
+
 pytestmark = pytest.mark.gpu
 OUT_TOL = 1e-3   # north_star: within 1e-3 on fp16 outputs — flat absolute bound, rtol = 0
 
@@ -49,6 +51,11 @@ def _report_stable(what, n_stable, n_dec, frac, floor):
         pass
 
 
+# Floors of the BOUND fraction per config.  The fraction is a property of the ORACLE and the seeded inputs (how many decisions the
+# reference itself flips under +-2e-5, with a head dropped at its first such draw), not of the HIP path — every bound decision must
+# match whatever the fraction is.  Measured (round 4, gpurun_out/stable_fractions.txt): configs[1] and [2] 1.0000 / >= 0.95,
+# configs[3] 453/485 = 0.934 and configs[4] 550/590 = 0.932: a 96-victim draw out of ~5000 columns has a threshold pair within 2e-5
+# in about one of 25 draws, and a head leaves the count at its first one.
 def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaForCausalLM", min_stable=0.95):
     import easykv_amd
     from oracle import easykv_oracle as O
@@ -105,7 +112,7 @@ def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaFo
     assert len(model.outputs_log) == len(ref_model.outputs_log)
     for f in range(min(first_div, len(model.outputs_log))):
         a, b = model.outputs_log[f], ref_model.outputs_log[f]
-        assert torch.allclose(a, b, rtol=0, atol=OUT_TOL), (f, float((a - b).abs().max()))
+        assert out_close(a, b, OUT_TOL), (f, float((a - b).abs().max()))
     return res, tr, frac
 
 
@@ -149,7 +156,7 @@ def test_config4_llama13b_heads_ppl_streaming_stride96_full_geometry():
     ratio = 4096 / 10253
     assert geometry("ppl", 10253, ratio, 96) == (4192, 4109, 77)
     cfg = dict(budget=ratio, kv_policy="roco", streaming=True, temp_length=4, recent_ratio=0.1)
-    res, tr, frac = _run_pair("ppl", 96, cfg, 1, 40, 40, 128, 10253, seed=1313, min_stable=0.8)
+    res, tr, frac = _run_pair("ppl", 96, cfg, 1, 40, 40, 128, 10253, seed=1313, min_stable=0.92)
     assert tr.cache_len == 4109
     assert abs(res - float(tr.result)) <= 1e-6 * abs(float(tr.result))
 
@@ -163,7 +170,7 @@ def test_config3_vicuna_passkey_stride96_full_geometry():
     from easykv_amd import geometry
     assert geometry("encoding", 9994, 0.5, 96) == (5093, 5002, 4906)
     cfg = dict(budget=0.5, kv_policy="roco", max_new_tokens=3, temp_length=4, recent_ratio=0.1)
-    res, tr, frac = _run_pair("encoding", 96, cfg, 1, 32, 32, 128, 9994, seed=9994)
+    res, tr, frac = _run_pair("encoding", 96, cfg, 1, 32, 32, 128, 9994, seed=9994, min_stable=0.92)
     assert tr.report.strip() == "KV cache budget ratio: 50.05%(5002/9994)"
     assert tr.cache_len == 5002 + 3
     assert res == " ".join(str(t) for t in tr.result)

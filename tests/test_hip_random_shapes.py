@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.golden_util import out_close
+
 from tests.test_hip_fullsize import Probe
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +55,7 @@ def test_random_decode_runs(seed):
                     continue        # this layer's trajectories have legitimately diverged; stop following it
                 o_ref, ids_ref = O.layer_step(sts[l], qs[l:l + 1, :, t:t + 1].float(), ks[l:l + 1, :, t:t + 1].float(), vs[l:l + 1, :, t:t + 1].float(),
                                               O.StepPlan(policy=policy, phase="decode", evict=evict, score_off=P, budget=budget))
-                assert torch.allclose(out[l].float().cpu(), o_ref[0], atol=1e-3, rtol=0), (seed, i, l)
+                assert out_close(out[l].float().cpu(), o_ref[0]), (seed, i, l)
                 if evict:
                     same = ids[l, :, 0].cpu().long() == ids_ref[:, 0] + P
                     ok = ~probe.last_unstable
@@ -94,7 +96,7 @@ def test_random_chunk_runs(seed):
                       tova_head_mean=bool(seed % 2))
             out, ids = bank.attend(StepPlan(n_split=n_split, **kw), q.cuda(), k.cuda(), v.cuda())
             o_ref, ids_ref = O.layer_step(st, q.float(), k.float(), v.float(), O.StepPlan(**kw))
-            assert torch.allclose(out[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0), (seed, step)
+            assert out_close(out[0].float().cpu(), o_ref[0]), (seed, step)
             got, ref = torch.sort(ids[0].cpu().long(), dim=-1)[0], torch.sort(ids_ref, dim=-1)[0]
             ok = ~probe.last_unstable
             assert bool((got == ref).all(dim=-1)[ok].all()), (seed, step, D, H, rep, s, policy, n_split)
@@ -155,7 +157,7 @@ def test_random_wide_chunk_runs(seed, two_pass):
                 if not bool(alive[l]):
                     continue
                 o_ref, ids_ref = O.layer_step(sts[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw), cos, sin)
-                assert torch.allclose(out[l].float().cpu(), o_ref[0], atol=1e-3, rtol=0), (seed, step, l, D, H, rep, s, stream)
+                assert out_close(out[l].float().cpu(), o_ref[0]), (seed, step, l, D, H, rep, s, stream)
                 if step == 0:
                     if policy != "tova":
                         assert torch.allclose(bank.score_sum[l, :, :idx].cpu(), sts[l].s[:, :idx], rtol=3e-5, atol=1e-7), (seed, l)
@@ -222,7 +224,7 @@ def test_random_long_decode_runs(seed):
                 if not bool(alive[l].all()):
                     continue
                 o_ref, ids_ref = O.layer_step(sts[l], q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw), cos, sin)
-                assert torch.allclose(out[l].float().cpu(), o_ref[0], atol=1e-3, rtol=0), (seed, i, l, D, H, rep, budget, stream)
+                assert out_close(out[l].float().cpu(), o_ref[0]), (seed, i, l, D, H, rep, budget, stream)
                 same = ids[l, :, 0].cpu().long() == ids_ref[:, 0] + P
                 ok = ~probe.last_unstable
                 assert bool(same[ok].all()), (seed, i, l, D, H, rep, policy, n_split, budget, P, stream)
@@ -262,7 +264,7 @@ def test_long_run_steady_state_decode_against_the_oracle(policy, D, rep):
             for l in range(L):
                 st = O.LayerState(k=kord[l:l + 1], v=vord[l:l + 1], s=rows[0][l], q=rows[1][l], c=rows[2][l])
                 o_ref, ids_ref = O.layer_step(st, q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw))
-                assert torch.allclose(out[l].float().cpu(), o_ref[0], atol=1e-3, rtol=0), (i, l)
+                assert out_close(out[l].float().cpu(), o_ref[0]), (i, l)
                 same = ids[l, :, 0].cpu().long() == ids_ref[:, 0]
                 ok = ~probe.last_unstable
                 assert bool(same[ok].all()), (i, l, policy, D, rep)
@@ -339,7 +341,7 @@ def test_one_launch_chunk_step_equals_two_launches_and_the_oracle(seed):
             assert torch.equal(banks["one"].slot_of_pos, banks["two"].slot_of_pos)
             if follow:
                 o_ref, ids_ref = O.layer_step(st, q[:1].float(), k[:1].float(), v[:1].float(), O.StepPlan(**kw), cos, sin)
-                assert torch.allclose(o1[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0), (seed, step, D, H, rep, s, stream)
+                assert out_close(o1[0].float().cpu(), o_ref[0]), (seed, step, D, H, rep, s, stream)
                 if kw["evict"]:
                     got, ref = torch.sort(i1[0].cpu().long(), dim=-1)[0], torch.sort(ids_ref, dim=-1)[0]
                     ok = ~probe.last_unstable
@@ -407,10 +409,10 @@ def test_logits_in_lds_chunk_step_matches_the_two_launch_path_and_the_oracle(see
             o1, i1 = banks["lds"].attend(StepPlan(**kw), q.cuda(), k.cuda(), v.cuda())
             o2, i2 = banks["two"].attend(StepPlan(n_split=1, two_pass=-1, **kw), q.cuda(), k.cuda(), v.cuda())
             if same:
-                assert torch.allclose(o1.float(), o2.float(), atol=1e-3, rtol=0), (seed, step)
+                assert out_close(o1.float(), o2.float()), (seed, step)
             o_ref, ids_ref = O.layer_step(st, q[:1].float(), k[:1].float(), v[:1].float(), O.StepPlan(**kw))
             if follow:
-                assert torch.allclose(o1[0].float().cpu(), o_ref[0], atol=1e-3, rtol=0), (seed, step, D, H, rep, s)
+                assert out_close(o1[0].float().cpu(), o_ref[0]), (seed, step, D, H, rep, s)
                 if kw["evict"]:
                     got, ref = torch.sort(i1[0].cpu().long(), dim=-1)[0], torch.sort(ids_ref, dim=-1)[0]
                     ok = ~probe.last_unstable
