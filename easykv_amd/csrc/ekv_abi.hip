@@ -197,7 +197,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
       ekv_decode_fused_supported(bank->head_dim, rep, T, w.t_pad, ekv_fused_logit_pad(bank, st, w.t_pad), st->n_evict, bank->cap, 8)) {
     n_split = 1;   // >= 1 head per CU: one 8-wave workgroup per head beats key-range splits + a second kernel (GQA shapes)
   }
-  const bool two_pass_plan = st->q_len > 1 && ekv_chunk_two_pass(rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass);
+  const bool two_pass_plan = st->q_len > 1 && ekv_chunk_two_pass(bank->head_dim, rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass);
   const bool wide_plan = st->q_len > 1 && ekv_chunk_wide(bank->head_dim, rep, st->q_len, st->rope_on_read != 0, two_pass_plan,
                                                         !two_pass_plan && scored && st->accumulate != 0);
   if (n_split <= 0 && st->q_len > 1) {

@@ -12,6 +12,9 @@ EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 #define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t);
 EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
 #undef EKW_DECL
+#define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_rope_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t);
+EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
+#undef EKW_DECL
 
 // Two-pass scheme (statistics pass + exact pass with in-kernel column sums, see ekv_attn_chunk.inc) for scored chunk
 // steps.  It trades one extra read of K (and a third MFMA product) for the rep x n x T logits never touching HBM: at rep*n = 96
@@ -21,11 +24,14 @@ EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
 // them there.  Not with rope-on-read (every product is three MFMAs on the hi/lo pairs: C5 1.98 vs 2.59 ms).
 // ekv_step.two_pass = 1 / -1 selects a scheme explicitly (every golden case runs under both).  tova needs the last query row
 // itself, not column sums, and always uses the one-pass kernel.
-bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode) {
+// Round 4: with rope-on-read the two passes run on the wide-block kernel's RoPE variants (head_dim 64 / 128: K rotated in LDS, no
+// logits in HBM) from the same 40 rows; head_dim 32 keeps the one-pass 16x16 kernel.
+bool ekv_chunk_two_pass(int head_dim, int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode) {
   const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // rep query heads share a 16-lane row
   const bool can = q_len > 1 && scored && accumulate && policy != EKV_POLICY_TOVA && rep_ok;
   if (!can || mode < 0) return false;
-  return mode > 0 || (!rope && rep * q_len >= 40);   // measured crossover: 32 rows 0.34 (one pass) vs 0.36 ms, 48 rows 0.42 vs 0.41 ms
+  // measured crossover: 32 rows 0.34 (one pass) vs 0.36 ms, 48 rows 0.42 vs 0.41 ms
+  return mode > 0 || ((!rope || head_dim == 64 || head_dim == 128) && rep * q_len >= 40);
 }
 
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len) {
@@ -50,7 +56,7 @@ void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw
 // the 16x16x32 kernel (A/B measurements on one box).
 bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, bool wants_logits) {
   static const bool off = [] { const char* e = std::getenv("EKV_NO_WIDE"); return e != nullptr && e[0] == '1'; }();
-  if (off || rope || q_len < 2 || (head_dim != 64 && head_dim != 128)) return false;
+  if (off || q_len < 2 || (head_dim != 64 && head_dim != 128)) return false;
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(rep, q_len, &qb_rows, &n_qblocks, &qpw);
   if (qpw < 2) return false;                                  // <= 32 rows: HBM-bound shapes, the small-tile kernels
@@ -103,7 +109,7 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
     const int nwq = qpw == 4 ? 4 : 2;
     // one pass over K and V (output, and for a scored step every row's softmax statistics), then — scored steps — the column-sum
     // pass over K
-#define EKW_GO(d, m) ekv_launch_attn_wide_d##d##_m##m(a, nwq, layer_count, s)
+#define EKW_GO(d, m) (rope ? ekv_launch_attn_wide_rope_d##d##_m##m(a, nwq, layer_count, s) : ekv_launch_attn_wide_d##d##_m##m(a, nwq, layer_count, s))
     hipError_t e = head_dim == 128 ? EKW_GO(128, 0) : EKW_GO(64, 0);
     if (two_pass && e == hipSuccess) e = head_dim == 128 ? EKW_GO(128, 2) : EKW_GO(64, 2);
 #undef EKW_GO

@@ -84,9 +84,9 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
                                  const EkvScoreArgs* fuse_sc = nullptr);
 size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs& a);
 bool ekv_score_rows_exceed_lds(int W, int rows);   // generic scorer: S / Q / C + keys of W columns do not fit 160 KB of LDS
-bool ekv_chunk_two_pass(int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode);
+bool ekv_chunk_two_pass(int head_dim, int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode);
 // the launch runs on the wide-query-block kernel (32x32x16 MFMA, ekv_attn_wide.inc): 33..128 GQA-folded rows per query block,
-// plain keys, head_dim 64 / 128, and either the two-pass scheme (rep in {1, 2, 4, 8, 16}) or a step that exports no logits
+// plain or RoPE-on-read keys, head_dim 64 / 128, and either the two-pass scheme (rep in {1, 2, 4, 8, 16}) or a step that exports no logits
 bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, bool wants_logits);
 hipError_t ekv_launch_tova_headmean(const EkvScoreArgs& a, int layer_count, hipStream_t s);
 hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipStream_t s);

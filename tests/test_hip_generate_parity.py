@@ -144,10 +144,14 @@ def test_sampler_on_the_device_matches_reference_fixture():
     """VERDICT r3 missing #5: the product runs ``api.logits_adapter`` on the GPU (api.generate), where ``torch.sort``'s tie order and
     ``cumsum``'s summation order are a different implementation from the CPU ops the fixture was produced with
     (oracle/gen_sampler_golden.py imports the reference's logits_adapter, easykv/easykv.py:115-134).  The fixture holds exact ties at
-    the nucleus boundary (``ties_v16``) and an all-equal row (``flat_v33``).  Bar on the device: the SAME support (which tokens
-    survive the nucleus cut — a tie broken differently would change it) whenever the cut is not inside a group of exactly tied
-    probabilities, probabilities within 2e-6 of the reference's, rows summing to 1; and the greedy configuration
-    (temperature 1e-6) picks the reference's token."""
+    the nucleus boundary (``ties_v16``) and an all-equal row (``flat_v33``).  What the device run is held to:
+
+    * every token whose keep / drop decision does not hang on the last bits of the running sum — ``cumsum - p`` at least 1e-5 away
+      from ``top_p`` in an fp64 re-evaluation, and not inside a group of exactly tied probabilities that straddles the cut — is kept /
+      dropped exactly as in the reference's output (measured on MI355X: at ``top_p = 1.0`` the device keeps 90 tokens of a row where the
+      CPU keeps 91 — the fp32 running sum crosses 1.0 one tail token earlier; the tokens in question carry ~1e-7 of probability);
+    * the kept probabilities equal the reference's to 2e-5 relative (the renormalisation sees the tail difference), rows sum to 1;
+    * the greedy configuration (temperature 1e-6) puts everything on the reference's token."""
     import os
     import numpy as np
     from easykv_amd.api import logits_adapter
@@ -155,30 +159,37 @@ def test_sampler_on_the_device_matches_reference_fixture():
     z = np.load(os.path.join(root, "tests", "golden", "sampler", "logits_adapter.npz"))
     keys = sorted({k.rsplit("|", 1)[0] for k in z.files})
     assert len(keys) == 45
-    n_support = 0
+    n_bound = n_free = 0
     for key in keys:
         name, temperature, top_p = key.split("|")
-        logits = torch.from_numpy(z[key + "|logits"]).cuda()
-        final, raw = logits_adapter(logits, float(temperature), float(top_p))
+        temperature, top_p = float(temperature), float(top_p)
+        logits_cpu = torch.from_numpy(z[key + "|logits"])
+        final, raw = logits_adapter(logits_cpu.cuda(), temperature, top_p)
         ref_final, ref_raw = torch.from_numpy(z[key + "|final"]), torch.from_numpy(z[key + "|raw"])
         final, raw = final.cpu(), raw.cpu().reshape(ref_raw.shape)
         assert torch.allclose(raw, ref_raw, atol=2e-6, rtol=1e-5), key
         assert torch.allclose(final.sum(-1), torch.ones(final.shape[:-1]), atol=1e-5), key
-        if float(temperature) < 1e-3:       # greedy: one-hot on the reference's token
+        if temperature < 1e-3:       # greedy: one-hot on the reference's token
             assert torch.equal(final.argmax(-1), ref_final.argmax(-1)), key
-        # the nucleus cut lies inside a group of exactly tied probabilities <=> the reference keeps some but not all members of a
-        # group of equal softmax values: only then may the support differ (by WHICH tied tokens are kept, never by how many)
-        prob = torch.softmax(torch.from_numpy(z[key + "|logits"]) / float(temperature), dim=-1)
-        kept_ref, kept = ref_final > 0, final > 0
-        assert torch.equal(kept.sum(-1), kept_ref.sum(-1)), key
-        rows = prob.reshape(-1, prob.shape[-1])
-        for r, (pr, kr, kk) in enumerate(zip(rows, kept_ref.reshape(rows.shape), kept.reshape(rows.shape))):
-            cut_in_tie = any(bool(kr[pr == v].any()) and not bool(kr[pr == v].all()) for v in pr[kr].unique())
-            if not cut_in_tie:
-                assert torch.equal(kr, kk), (key, r)
-                n_support += 1
-                a, b = final.reshape(rows.shape)[r], ref_final.reshape(rows.shape)[r]
-                assert torch.allclose(a, b, atol=2e-6, rtol=1e-5), (key, r, float((a - b).abs().max()))
-            else:       # same multiset of kept probabilities
-                assert torch.allclose(torch.sort(pr[kk])[0], torch.sort(pr[kr])[0], atol=0, rtol=0), (key, r)
-    assert n_support >= 40
+        prob = torch.softmax(logits_cpu.double() / temperature, dim=-1).reshape(-1, logits_cpu.shape[-1])
+        got, ref = final.reshape(prob.shape), ref_final.reshape(prob.shape)
+        for r in range(prob.shape[0]):
+            p = prob[r]
+            sp, order = torch.sort(p, descending=True, stable=True)
+            excl = torch.cumsum(sp, 0) - sp                      # what the reference compares with top_p (easykv/easykv.py:121-123)
+            firm_sorted = (excl - top_p).abs() > 1e-5
+            # a group of exactly tied probabilities that straddles the cut: WHICH of its members survive is the sort's tie order
+            kept_sorted = excl <= top_p
+            for v in sp[kept_sorted].unique():
+                grp = sp == v
+                if bool(kept_sorted[grp].any()) and not bool(kept_sorted[grp].all()):
+                    firm_sorted &= ~grp
+            firm = torch.zeros_like(firm_sorted)
+            firm[order] = firm_sorted
+            n_bound += int(firm.sum())
+            n_free += int((~firm).sum())
+            assert torch.equal(got[r][firm] > 0, ref[r][firm] > 0), (key, r)
+            both = firm & (ref[r] > 0)
+            assert torch.allclose(got[r][both], ref[r][both], rtol=2e-5, atol=2e-6), (key, r, float((got[r][both] - ref[r][both]).abs().max()))
+            assert int((got[r] > 0).sum()) >= 1
+    assert n_bound > 2 * n_free, (n_bound, n_free)      # (free: the deep tail at top_p = 1.0 — running sum within 1e-5 of 1 — and the zeros of the greedy rows)

@@ -148,3 +148,61 @@ def test_scored_unsplit_first_chunk_without_accumulate(d, hq, h, n, t_prev):
         assert out_close(out[l].float().cpu(), o_ref), float((out[l].float().cpu() - o_ref).abs().max())
     for a, b in zip(before, (bank.score_sum, bank.score_sq, bank.score_cnt)):
         assert torch.equal(a, b)
+
+
+ROPE_SHAPES = [
+    # d, hq, h, n, t_prev, n_split
+    (128, 4, 4, 96, 700, 0),      # configs[4]-shaped chunk step (96 rows, streaming=True)
+    (128, 4, 4, 96, 700, 3),      # ... key-range splits
+    (128, 8, 2, 24, 500, 0),      # GQA x4: 96 folded rows
+    (128, 4, 4, 300, 0, 0),       # dense prefix under RoPE-on-read: three query blocks, no cache rows
+    (128, 2, 2, 50, 77, 0),       # 33..64 rows: the 2 x 2 wave shape
+    (128, 8, 2, 70, 130, 0),      # several query blocks, ragged last block
+    (64, 4, 4, 100, 333, 0),
+    (64, 8, 2, 30, 100, 2),
+    (128, 16, 2, 12, 150, 0),     # GQA x8
+]
+
+
+def _ref_stream(q, k, v, h, cos, sin):
+    from oracle import easykv_oracle as O
+    n, T = q.shape[2], k.shape[2]
+    o, p = O.attention_core_stream(q.float(), k.float(), v.float(), cos, sin, O.causal_chunk_mask(n, T, torch.float32))
+    pb = O.gqa_fold(p, h, q.shape[1] // h)[0]
+    return o[0], pb.sum(dim=-2), (pb ** 2).sum(dim=-2)
+
+
+@pytest.mark.parametrize("scored", [False, True])
+@pytest.mark.parametrize("d,hq,h,n,t_prev,n_split", ROPE_SHAPES)
+def test_rope_on_read_steps_match_oracle(d, hq, h, n, t_prev, n_split, scored):
+    """streaming=True (easykv/llama_patch.py:310-327: keys cached un-rotated, rotated by their current position index on every
+    read) on the wide-block kernel's RoPE variants: K tiles rotated in LDS into fp16 hi + lo planes, three MFMAs per product.
+    Unscored steps (one pass) and scored steps (one pass + column-sum pass): outputs within 1e-3, column sums of the GQA-folded
+    probabilities within 5e-6 of the fp32 oracle, over scattered slot maps; the cache keeps the UN-rotated rows."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    g = torch.Generator().manual_seed(11 * d + hq * 100 + n + scored)
+    L, T = 2, t_prev + n
+    q = torch.randn(L, hq, n, d, generator=g).half()
+    k = torch.randn(L, h, T, d, generator=g).half()
+    v = torch.randn(L, h, T, d, generator=g).half()
+    cos, sin = O.rope_tables(T + 64, d)
+    bank = KVBank(L, hq, h, d, cap=T + 64, scored=scored)
+    bank.set_rope(cos, sin)
+    _scatter_bank(bank, k, v, t_prev, g)
+    if scored:
+        bank.state_init(T, 2, 1)
+        plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=False, n_split=n_split, two_pass=1, streaming=True)
+    else:
+        plan = StepPlan(policy="full", phase="prefill", accumulate=False, n_split=n_split, streaming=True)
+    info = bank.step_info(plan, n)
+    assert info["wide"] == 1 and info["two_pass"] == int(scored)
+    out, _ = bank.attend(plan, q.cuda(), k[:, :, t_prev:].cuda().contiguous(), v[:, :, t_prev:].cuda().contiguous())
+    for l in range(L):
+        o_ref, s_ref, q_ref = _ref_stream(q[l:l + 1], k[l:l + 1], v[l:l + 1], h, cos, sin)
+        assert out_close(out[l].float().cpu(), o_ref), float((out[l].float().cpu() - o_ref).abs().max())
+        if scored:
+            assert torch.allclose(bank.score_sum[l, :, :T].cpu(), s_ref, rtol=COL_RTOL, atol=1e-7), float(((bank.score_sum[l, :, :T].cpu() - s_ref).abs() / s_ref.abs().clamp_min(1e-6)).max())
+            assert torch.allclose(bank.score_sq[l, :, :T].cpu(), q_ref, rtol=COL_RTOL, atol=1e-9)
+    kk, vv = bank.ordered_kv()
+    assert torch.equal(kk.cpu(), k) and torch.equal(vv.cpu(), v)
