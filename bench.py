@@ -171,7 +171,7 @@ def event_overhead_us(dev, reps=32):
     return v[len(v) // 2]
 
 
-def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="encoding", budget=0.5, streaming=False, shape=None):
+def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="encoding", budget=0.5, streaming=False, shape=None, pmc=True):
     """Secondary figures (never `value`): the chunk phase of a strided prefill (SURVEY.md §8d Bench-P).  Default = BASELINE.json
     configs[1]: S=4096, stride 8, budget 0.5, kv_policy roco; also run at stride 64 / 96 and at the configs[3] shape
     (S=9994, stride 96).  The cache oscillates idx <-> idx+stride, every chunk step attends the retained slots with `stride`
@@ -229,7 +229,7 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="enco
     T = idx + stride
     n_state = {"roco": 3, "h2o_head": 1, "tova": 1}[plan.policy]
     by = algorithmic_bytes(H, Hq, D, T, stride, n_state)
-    traffic, traffic_src = (None, None) if (streaming or shape is not None) else prefill_pmc(S, stride, L, Hq, H, D, plan.policy)
+    traffic, traffic_src = (None, None) if (streaming or shape is not None or not pmc) else prefill_pmc(S, stride, L, Hq, H, D, plan.policy)
     gbs = by["total"] * L / t_step / 1e9
     return {"workload": f"bench-P chunk phase: S={S} stride={stride} budget={budget:.4g} ({mode} geometry) -> idx={idx}, T={T}, L={L} Hq={Hq} H={H} D={D} "
                         f"kv_policy={plan.policy}" + (", streaming=True (RoPE by slot index on every read)" if streaming else ""),
@@ -356,7 +356,7 @@ def dense_prefix_scored(args, dev, n, kv_heads, stride, label, reps=3):
                          "frac": fl / t / 1e12 / MFMA_F16_PEAK_TFLOPS, "flops": fl, "mfma_flops_executed": 1.5 * fl, "traffic": None}}
 
 
-def live_pmc_step(script_args, script, timeout_s=150):
+def live_pmc_step(script_args, script, timeout_s=150, env=None):
     """HBM traffic of ONE chunk step whose work is several launches (statistics pass + exact pass + scorer), measured in THIS run:
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` in separate counter-only passes over a short child run of ``script``; the
     bytes of every launch of the path's kernels are summed and divided by the number of steps (= launches of the scorer, one per
@@ -369,13 +369,13 @@ def live_pmc_step(script_args, script, timeout_s=150):
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None:
         return None, "rocprofv3 not found"
-    names = ("ekv_attn_wide_kernel", "ekv_attn_chunk_kernel", "ekv_score_select_kernel", "ekv_chunk_lds_kernel")
+    names = ("ekv_attn_wide_kernel", "ekv_attn_chunk_kernel", "ekv_score_select_kernel", "ekv_chunk_lds_kernel", "ekv_rope_q_kernel", "ekv_fold_kernel")
     tot, steps = {}, 0
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ekv_pmc_", dir="/tmp")
         try:
             subprocess.run([rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, script] + script_args, cwd="/tmp",
-                           env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+                           env=dict(os.environ, TMPDIR="/tmp", **(env or {})), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == ctr and any(n in r["Kernel_Name"] for n in names)] if fs else []
         except Exception as e:
@@ -387,7 +387,8 @@ def live_pmc_step(script_args, script, timeout_s=150):
             return None, f"live PMC pass saw {steps} steps"
         tot[ctr] = sum(float(r["Counter_Value"]) for r in rows) / steps
     return ((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0,
-            f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_chunk.py {' '.join(script_args)}, "
+            f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_chunk.py {' '.join(script_args)}"
+            f"{(' [' + ' '.join(k + '=' + v for k, v in env.items()) + ']') if env else ''}, "
             "all launches of a step summed, 2 x FETCH + WRITE (gfx950 correction, KiB -> bytes)")
 
 
@@ -477,6 +478,95 @@ def boundary_kernels(args, dev, iters=6):
     for name in out:
         out[name]["frac_of_hbm_peak"] = out[name]["gbs"] / HBM_PEAK_GBS
     out["shape"] = f"L={L} H={H} T={T} D={D} fp16"
+    return out
+
+
+def stage_workloads(args, dev, budget, policy):
+    """Secondary figures: what ONE RANK of the layer-sharded model runs per step at N = 2 / 4 / 8 (strong scaling) —
+    the Bench-D decode step with 16 / 8 / 4 of the 32 layers in one launch — measured on this one GPU so that the first real 1/2/4/8
+    curve can be checked against a prediction: us per step, the library's plan (one fused launch or attention +
+    scorer launches, key-range splits), the roofline fraction on the algorithmic bytes of those layers.  Same steady-state
+    preparation as the headline run (scattered slot map, pre-warmed score rows).  Plus the configs[3] chunk step with 4 layers."""
+    from easykv_amd import KVBank, StepPlan, geometry
+    Hq, D = args.heads, args.head_dim
+    H = args.kv_heads or Hq
+    T = budget + 1
+    n_state = {"roco": 3, "h2o_head": 1, "tova": 1}.get(policy, 0)
+    b = algorithmic_bytes(H, Hq, D, T, 1, n_state)
+    out = []
+    for L in (16, 8, 4):
+        if L >= args.layers:
+            continue
+        gen = torch.Generator(device=dev).manual_seed(77 + L)
+        bank = KVBank(L, Hq, H, D, cap=T + 63, device=dev)
+        bank.load_rows(torch.randn(L, H, budget, D, generator=gen, device=dev).half(), torch.randn(L, H, budget, D, generator=gen, device=dev).half())
+        bank.slot_of_pos[:, :, :budget] = torch.argsort(torch.rand(L, H, budget, generator=gen, device=dev), dim=-1).int()
+        bank.state_init(T, 0)
+        n_in = 64
+        qs = torch.randn(n_in, L, Hq, 1, D, generator=gen, device=dev).half()
+        ks = torch.randn(n_in, L, H, 1, D, generator=gen, device=dev).half()
+        vs = torch.randn(n_in, L, H, 1, D, generator=gen, device=dev).half()
+        o = torch.empty(L, Hq, 1, D, dtype=torch.float16, device=dev)
+        ids = torch.empty(L, H, 1, dtype=torch.int32, device=dev)
+        plan = StepPlan(policy=policy, phase="decode", evict=True, score_off=0, budget=budget)
+        if policy == "recency":
+            plan.range_start = 0
+        n_split, fused = bank.step_plan(plan, 1)
+        t_end = time.perf_counter() + 0.25            # pre-warm: clocks + score state
+        i = 0
+        while time.perf_counter() < t_end:
+            for _ in range(32):
+                bank.attend(plan, qs[i % n_in], ks[i % n_in], vs[i % n_in], out=o, evict_ids=ids)
+                i += 1
+            torch.cuda.synchronize(dev)
+        n = 512
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for j in range(n):
+            bank.attend(plan, qs[(i + j) % n_in], ks[(i + j) % n_in], vs[(i + j) % n_in], out=o, evict_ids=ids)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        t = ev[0].elapsed_time(ev[1]) / n * 1e-3
+        gbs = b["total"] * L / t / 1e9
+        out.append({"workload": f"decode step of a {L}-layer stage (one rank of N={args.layers // L}, strong scaling): L={L} Hq={Hq} H={H} D={D} T={T} {policy}",
+                    "layers_in_launch": L, "us_per_step": t * 1e6, "plan": {"fused_one_launch": bool(fused), "n_split": n_split},
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "bytes_per_step": b["total"] * L, "timing": "one HIP event pair around 512 back-to-back steps"},
+                    "predicted_pipeline_tokens_per_s": 1.0 / t})
+        del bank
+    # the configs[3] chunk step of a 4-layer stage (N = 8)
+    S, stride, L = 9994, 96, 4
+    if L < args.layers:
+        bp, idx, _ = geometry("encoding", S, 0.5, stride)
+        gen = torch.Generator(device=dev).manual_seed(4321)
+        rnd = lambda h, m: torch.randn(L, h, m, D, generator=gen, device=dev).half()
+        bank = KVBank(L, Hq, H, D, cap=idx + stride, device=dev)
+        bank.load_rows(rnd(H, idx), rnd(H, idx))
+        bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=gen, device=dev), dim=-1).int()
+        bank.state_init(idx + stride, 2, stride)
+        plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=bp, recent=int(bp * 0.1), sink=4, stride=stride)
+        ins = [(rnd(Hq, stride), rnd(H, stride), rnd(H, stride)) for _ in range(4)]
+        o = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
+        ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
+        n_split, fused = bank.step_plan(plan, stride)
+        for j in range(24):
+            bank.attend(plan, *ins[j % 4], out=o, evict_ids=ids)
+        n = 48
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for j in range(n):
+            bank.attend(plan, *ins[j % 4], out=o, evict_ids=ids)
+        ev[1].record()
+        torch.cuda.synchronize(dev)
+        t = ev[0].elapsed_time(ev[1]) / n * 1e-3
+        by = algorithmic_bytes(H, Hq, D, idx + stride, stride, 3)
+        gbs = by["total"] * L / t / 1e9
+        out.append({"workload": f"configs[3] chunk step of a 4-layer stage (one rank of N=8): S={S} stride={stride} T={idx + stride} L={L} Hq={Hq} H={H} D={D} roco",
+                    "layers_in_launch": L, "us_per_step": t * 1e6, "plan": {"fused_one_launch": bool(fused), "n_split": n_split},
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "bytes_per_step": by["total"] * L},
+                    "predicted_pipeline_prompt_tokens_per_s": stride / t})
+        del bank
     return out
 
 
@@ -838,6 +928,8 @@ def main():
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
                                      "bytes_per_step_launches": b["total"] * lc0, "avg_us": (t_attn + t_score) * 1e6,
                                      "score_select_us": t_score * 1e6}
+        if world == 1 and not args.no_prefill and not args.graph and (args.layers, Hq, H, D) == (32, 32, 32, 128):
+            line["stage_workloads"] = stage_workloads(args, dev, budget, args.policy)
         if world == 1 and not args.no_prefill and not args.graph:
             line["strided_prefill"] = strided_prefill(args, dev)
             sp = line["strided_prefill"]
@@ -857,8 +949,11 @@ def main():
                                                             streaming=True, shape=(40, 40, 40))]
             if not args.no_live_pmc and (args.layers, Hq, H, D, args.policy) == (32, 32, 32, 128, "roco"):
                 # wide strides: a step is several launches (statistics pass, exact pass, scorer) — all of them measured in this run
-                for spm, sargs in ((line["strided_prefill_more"][0], ["4096", "64", "8"]), (line["strided_prefill_more"][2], ["9994", "96", "6"])):
-                    live, live_src = live_pmc_step(sargs, os.path.join(ROOT, "tools", "bench_chunk.py"))
+                more = line["strided_prefill_more"]
+                for spm, sargs, env in ((more[0], ["4096", "64", "8"], None), (more[1], ["4096", "96", "8"], None), (more[2], ["9994", "96", "6"], None),
+                                        (more[3], ["4096", "16", "8", "8"], {"BUDGET": "0.3"}),
+                                        (more[4], ["10253", "96", "5"], {"MODE": "ppl", "BUDGET": repr(4096 / 10253), "STREAMING": "1", "SHAPE": "40,40,40"})):
+                    live, live_src = live_pmc_step(sargs, os.path.join(ROOT, "tools", "bench_chunk.py"), env=env)
                     if live is not None:
                         spm["roofline"].update(traffic=live, traffic_source=live_src, traffic_over_algorithmic=live / spm["roofline"]["bytes_per_step"])
             line["dense_prefix"] = [dense_prefix(args, dev, 4096, 8), dense_prefix(args, dev, 9994, 96)]
@@ -869,6 +964,11 @@ def main():
             line["boundary_kernels"] = boundary_kernels(args, dev)
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args, budget, args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco")
+        # Key order of the ONE line: the contract keys first, the bulky secondary figures in the middle, and what a reader of a
+        # truncated tail must still see LAST — cpu_baseline, strided_prefill (BASELINE configs[1]) and roofline (the
+        # driver's stdout tail had lost configs[1]).
+        tail_keys = [k for k in ("stage_workloads", "per_layer_launches", "cpu_baseline", "strided_prefill", "roofline_step", "roofline") if k in line]
+        line = {**{k: v for k, v in line.items() if k not in tail_keys}, **{k: line[k] for k in tail_keys}}
         print(json.dumps(line))
     if world > 1:
         DS.barrier(dev)

@@ -17,6 +17,9 @@ stride = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 n_chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 48
 kvh = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 args = types.SimpleNamespace(layers=32, heads=32, kv_heads=kvh, head_dim=128, policy=os.environ.get("POLICY", "roco"), identity_layout=False)
-r = bench.strided_prefill(args, torch.device("cuda"), n_chunks=n_chunks, S=S, stride=stride)
+# other BASELINE shapes: MODE=ppl BUDGET=0.3995 STREAMING=1 SHAPE=40,40,40 (layers, query heads, KV heads)
+shape = tuple(int(x) for x in os.environ["SHAPE"].split(",")) if os.environ.get("SHAPE") else None
+r = bench.strided_prefill(args, torch.device("cuda"), n_chunks=n_chunks, S=S, stride=stride, mode=os.environ.get("MODE", "encoding"),
+                          budget=float(os.environ.get("BUDGET", "0.5")), streaming=os.environ.get("STREAMING", "0") == "1", shape=shape, pmc=False)
 print(json.dumps({"workload": r["workload"], "us_per_chunk_step": r["us_per_chunk_step"], "frac_of_hbm_peak": r["roofline"]["frac"],
                   "as_two_launches_us": r["as_two_launches_us"], "value": r["value"]}))
