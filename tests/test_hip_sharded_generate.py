@@ -263,3 +263,31 @@ def test_strided_prefill_pipelines_over_uneven_layer_blocks(world):
             assert len(x["t_send"]) == len(first["t_send"]) and max(x["run_ahead"] or [0]) <= 1
     if not overlapped:      # host clocks of different processes on a loaded box: evidence, not a correctness condition
         warnings.warn("no stage was observed running ahead of its successor in this run (timing-dependent)")
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_ranks_same_device_end_to_end(scaling):
+    """``bench.py --gpus 2`` exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node 2 ...``), both ranks
+    on ``cuda:0`` over gloo (``--same-device``: a gpurun box has one GPU; one rank per GPU over RCCL is the same code path with
+    backend nccl): the barrier-bracketed timed region, the stage hand-off, the max-over-ranks reduction, the second scaling mode, the
+    layer-sharded prefill pipeline — and ONE JSON line from rank 0 carrying the contract keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "4",
+           "--backend", "gloo", "--same-device", "--prewarm-s", "0.05", "--scaling", scaling, "--layers", "8", "--budget", "256"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["steps"] == 24 and line["scaling"] == scaling and line["value"] > 0
+    assert line["config"]["layers_per_rank"] == (4 if scaling == "strong" else 8)
+    assert line["second_scaling"]["scaling"] == ("weak" if scaling == "strong" else "strong") and line["second_scaling"]["value"] > 0
+    assert line["strided_prefill_pipeline"]["value"] > 0
+    assert "cpu_baseline" not in line            # (rank 0 at N = 1 only)
