@@ -3,7 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md: they do not fit one pass; never combined with a trace)
 # for the decode bench and for each strided-prefill shape.  Raw outputs -> gpurun_out/prof_$TAG; tools/summarize_prof.py
 # condenses them into profiles/${TAG}_*.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -25,6 +25,11 @@ for cfg in "c2 4096 8 24" "s64 4096 64 12" "c4 9994 96 8"; do
   run_pmc chunk_$1_fetch FETCH_SIZE python $R/tools/bench_chunk.py $2 $3 $4
   run_pmc chunk_$1_write WRITE_SIZE python $R/tools/bench_chunk.py $2 $3 $4
 done
+# BASELINE configs[4]: Llama2-13B heads, ppl geometry, streaming RoPE-on-read
+export MODE=ppl BUDGET=0.39949283136642936 STREAMING=1 SHAPE=40,40,40
+run_pmc chunk_c5_fetch FETCH_SIZE python $R/tools/bench_chunk.py 10253 96 6
+run_pmc chunk_c5_write WRITE_SIZE python $R/tools/bench_chunk.py 10253 96 6
+unset MODE BUDGET STREAMING SHAPE
 timeout 600 bash $R/tools/sq_counters.sh > $OUT/sq_counters.txt 2>&1
 cd $R
 timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err

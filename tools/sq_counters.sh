@@ -24,4 +24,7 @@ PY
   done
 }
 run "dense prefix 4906 tokens x 8 layers" python $R/tools/bench_prefix.py 4906 8
-run "C4 chunk step (S=9994 stride 96, two passes)" python $R/tools/bench_chunk.py 9994 96 4
+run "C4 chunk step (S=9994 stride 96: one pass + column-sum pass)" python $R/tools/bench_chunk.py 9994 96 4
+export MODE=ppl BUDGET=0.39949283136642936 STREAMING=1 SHAPE=40,40,40
+run "configs[4] chunk step (S=10253 stride 96, RoPE-on-read: one pass + column-sum pass)" python $R/tools/bench_chunk.py 10253 96 4
+unset MODE BUDGET STREAMING SHAPE

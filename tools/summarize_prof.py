@@ -69,7 +69,8 @@ def main(src, tag):
     json.dump(dec, open(f"profiles/{tag}_decode_summary.json", "w"), indent=1)
     pre = {}
     algo = dict(c2=("S=4096 stride=8 budget=0.5 (configs[1]): T=2064", 35663872 * 32), s64=("S=4096 stride=64: T=2176", None),
-                c4=("S=9994 stride=96 budget=0.5 (configs[3] shape): T=5098", None))
+                c4=("S=9994 stride=96 budget=0.5 (configs[3] shape): T=5098", None),
+                c5=("S=10253 stride=96 ppl geometry, streaming RoPE-on-read, L=Hq=H=40 (configs[4] shape): T=4205", None))
     for stem, (desc, _) in algo.items():
         c = combine(src, "chunk_" + stem)
         if c:
