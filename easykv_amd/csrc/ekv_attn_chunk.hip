@@ -66,12 +66,20 @@ bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, 
 
 // rope_on_read: q' = q*cos[pos] + rotate_half(q)*sin[pos] with pos = T - n + i (llama_patch.py:311, :326), once per step,
 // stored as an fp16 pair hi + lo (q' is an fp32 product; hi alone would cost ~5e-4 relative on the logits).
-__global__ void __launch_bounds__(128) ekv_rope_q_kernel(const EkvAttnArgs a, int D) {
-  const size_t row = (size_t)blockIdx.y * a.n_q_heads * a.q_len + blockIdx.x;   // (layer, q head, query)
-  const int i = blockIdx.x % a.q_len;
+__global__ void __launch_bounds__(256) ekv_rope_q_kernel(const EkvAttnArgs a, int D, int n_rows) {
+  // 256 / (D / 4) rows per workgroup, four consecutive d per thread (round 4: one 128-thread workgroup per row was 56 us of launch
+  // overhead per configs[4] step — 153 600 workgroups)
+  const int tpr = D / 4, rpb = 256 / tpr;
+  const int r_in = blockIdx.x * rpb + threadIdx.x / tpr;       // (q head, query) of this layer
+  if (r_in >= n_rows) return;
+  const size_t row = (size_t)blockIdx.y * n_rows + r_in;       // (layer, q head, query)
+  const int i = r_in % a.q_len;
   const int pos = a.n_slots - a.q_len + i;
   const __half* q = a.q + row * D;
-  for (int d = threadIdx.x; d < D; d += 128) {
+  const int d0 = (threadIdx.x % tpr) * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int d = d0 + e;
     const int dp = d < D / 2 ? d + D / 2 : d - D / 2;
     const float x = __half2float(q[d]), y = __half2float(q[dp]);
     const float qr = x * a.rope_cos[(size_t)pos * D + d] + (d < D / 2 ? -y : y) * a.rope_sin[(size_t)pos * D + d];
@@ -97,7 +105,8 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
   if (two_pass && fuse_sc != nullptr) return hipErrorInvalidValue;
   if (a.rope_cos != nullptr) {
     if (a.q_rot_hi == nullptr || a.q_rot_lo == nullptr) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ekv_rope_q_kernel, dim3(a.n_q_heads * a.q_len, layer_count), dim3(128), 0, s, a, head_dim);
+    const int n_rows = a.n_q_heads * a.q_len, rpb = 256 / (head_dim / 4);
+    hipLaunchKernelGGL(ekv_rope_q_kernel, dim3((n_rows + rpb - 1) / rpb, layer_count), dim3(256), 0, s, a, head_dim, n_rows);
   }
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
