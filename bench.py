@@ -324,8 +324,8 @@ def dense_prefix(args, dev, S, stride, reps=3):
 
 def dense_prefix_scored(args, dev, n, kv_heads, stride, label, reps=3):
     """Secondary figure: the SCORED dense prefix of a strided prefill with keep_attention=True (reference easykv.py:396, :403-405,
-    h2o_head_score :173-186: the prefix's probabilities seed S and Q): one step of ``n`` queries per layer — a statistics pass and
-    an exact pass with in-kernel column sums of the wide-block kernel (the query blocks are walked inside the launch; the r x r map
+    h2o_head_score :173-186: the prefix's probabilities seed S and Q): one step of ``n`` queries per layer — one pass for the
+    output and the row statistics and a K-only column-sum pass of the wide-block kernel (the query blocks are walked inside the launch; the r x r map
     never exists) + the scorer.  flops = the attention's own 4 * Hq * D * n^2 / 2 per layer (causal QK^T and PV); the two-pass
     scheme executes 1.5x that on the MFMA pipe (QK^T twice)."""
     from easykv_amd import KVBank, StepPlan
@@ -349,7 +349,7 @@ def dense_prefix_scored(args, dev, n, kv_heads, stride, label, reps=3):
         del bank
     t = sum(ms[1:]) / reps * 1e-3
     fl = 4.0 * Hq * D * n * n / 2 * L
-    return {"workload": f"scored dense causal prefix ({label}): {n} tokens, L={L} Hq={Hq} H={H} D={D}, keep_attention, statistics pass + exact "
+    return {"workload": f"scored dense causal prefix ({label}): {n} tokens, L={L} Hq={Hq} H={H} D={D}, keep_attention, one pass + column-sum "
                         f"pass + scorer over all layers (n_split={one_launch_set[0]})",
             "ms": t * 1e3, "value": n / t, "unit": "prompt tokens/s (scored prefix, attention path only)",
             "roofline": {"bound": "mfma", "achieved": fl / t / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -357,7 +357,7 @@ def dense_prefix_scored(args, dev, n, kv_heads, stride, label, reps=3):
 
 
 def live_pmc_step(script_args, script, timeout_s=150, env=None):
-    """HBM traffic of ONE chunk step whose work is several launches (statistics pass + exact pass + scorer), measured in THIS run:
+    """HBM traffic of ONE chunk step whose work is several launches (one pass + column-sum pass + scorer), measured in THIS run:
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` in separate counter-only passes over a short child run of ``script``; the
     bytes of every launch of the path's kernels are summed and divided by the number of steps (= launches of the scorer, one per
     step).  gfx950 correction as in live_pmc: 2 x FETCH_SIZE + WRITE_SIZE, KiB.  -> (bytes per step, source) or (None, reason)."""
@@ -413,7 +413,7 @@ def prefill_pmc(S, stride, L, Hq, H, D, policy):
         two = [v for n, v in ks.items() if "ekv_attn_chunk_kernel" in n or "ekv_attn_wide_kernel" in n or "ekv_score_select_kernel" in n]
         steps = [v["launches"] for n, v in ks.items() if "ekv_score_select_kernel" in n]
         if two and steps:
-            # launches per step from the launch counts: the statistics pass and the exact pass of the two-pass scheme carry the same
+            # launches per step from the launch counts: the two passes of the two-pass scheme may carry the same
             # kernel name (one template, two translation units), so that entry is the mean of the two and counts twice per step
             return (sum(v["hbm_bytes_per_launch"] * v["launches"] / steps[0] for v in two),
                     f"profiles/{os.path.basename(f)} [{stem}]: attention kernel launch(es) + scorer kernel of one step")
@@ -948,7 +948,7 @@ def main():
                                             strided_prefill(args, dev, S=10253, stride=96, n_chunks=8, warm=4, mode="ppl", budget=4096 / 10253,
                                                             streaming=True, shape=(40, 40, 40))]
             if not args.no_live_pmc and (args.layers, Hq, H, D, args.policy) == (32, 32, 32, 128, "roco"):
-                # wide strides: a step is several launches (statistics pass, exact pass, scorer) — all of them measured in this run
+                # wide strides: a step is several launches (one pass, column-sum pass, scorer) — all of them measured in this run
                 more = line["strided_prefill_more"]
                 for spm, sargs, env in ((more[0], ["4096", "64", "8"], None), (more[1], ["4096", "96", "8"], None), (more[2], ["9994", "96", "6"], None),
                                         (more[3], ["4096", "16", "8", "8"], {"BUDGET": "0.3"}),

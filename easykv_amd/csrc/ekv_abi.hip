@@ -246,7 +246,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   w.stats = w.colsum = nullptr;
   // column-sum partial rows per head: query-tile waves per workgroup x query blocks; the wide kernel combines them itself
   if (w.wide) {
-    // the exact pass of the wide kernel walks the query blocks of a (head, key range) inside the workgroup and leaves ONE row of
+    // the column-sum pass of the wide kernel walks the query blocks of a (head, key range) inside the workgroup and leaves ONE row of
     // column sums; a launch of few (head, layer) pairs (one layer of a decoder stack) spreads them over up to 16 workgroups
     const int wgs = st->layer_count * bank->n_kv_heads * w.n_split;
     w.n_col_parts = std::max(1, std::min(std::min(w.n_qblocks, 16), (512 + wgs - 1) / wgs));

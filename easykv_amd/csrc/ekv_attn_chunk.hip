@@ -16,7 +16,8 @@ EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
 EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
 #undef EKW_DECL
 
-// Two-pass scheme (statistics pass + exact pass with in-kernel column sums, see ekv_attn_chunk.inc) for scored chunk
+// Two-pass scheme (16x16 kernel: statistics pass + exact pass with in-kernel column sums, ekv_attn_chunk.inc; wide-block kernel: one
+// pass for output + row statistics, then a K-only column-sum pass, ekv_attn_wide.inc) for scored chunk
 // steps.  It trades one extra read of K (and a third MFMA product) for the rep x n x T logits never touching HBM: at rep*n = 96
 // the logits are 384 B per key against 512 B of K + V, written once and read once.  Measured on MI355X: in
 // round 1 the one-pass path won at every BASELINE shape (C4 1.89 vs 2.31 ms); with the round-2 instruction diet of the MFMA
@@ -60,7 +61,7 @@ bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, 
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(rep, q_len, &qb_rows, &n_qblocks, &qpw);
   if (qpw < 2) return false;                                  // <= 32 rows: HBM-bound shapes, the small-tile kernels
-  if (two_pass) return rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // the exact pass folds the rep query heads in registers
+  if (two_pass) return rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // the column-sum pass folds the rep query heads in registers
   return !wants_logits;
 }
 

@@ -78,7 +78,7 @@ def test_unscored_step_matches_oracle(d, hq, h, n, t_prev, n_split):
 
 @pytest.mark.parametrize("d,hq,h,n,t_prev,n_split", SHAPES)
 def test_scored_step_two_pass_matches_oracle(d, hq, h, n, t_prev, n_split):
-    """Modes 1 + 2 (statistics pass, exact pass with in-kernel column sums): scored accumulating steps."""
+    """Mode 0 with row statistics + mode 2 (K-only column-sum pass): scored accumulating steps."""
     from easykv_amd import KVBank, StepPlan
     g = torch.Generator().manual_seed(7 * d + hq * 100 + n)
     L, T = 2, t_prev + n
