@@ -570,6 +570,55 @@ def stage_workloads(args, dev, budget, policy):
     return out
 
 
+def per_layer_chunk_steps(args, dev, S, stride, n_steps=6, warm=3, mode="encoding", budget=0.5, streaming=False, shape=None):
+    """Secondary figure: a chunk step of the strided prefill issued ONE LAYER PER CALL, as a decoder stack does (layer l + 1's queries
+    depend on layer l's output): per layer the attention launches + fold, and — round 4, ekv_step.defer_layers for chunk steps — the
+    scorers of all layers in ONE launch at the end of the forward; ``immediate`` is the same step with every layer's scorer on the
+    critical path (rounds 1-3).  us per layer = wall time of a whole forward's calls / layers."""
+    from easykv_amd import KVBank, StepPlan, geometry
+    L, Hq, D = args.layers, args.heads, args.head_dim
+    H = args.kv_heads or Hq
+    if shape is not None:
+        L, Hq, H = shape
+    bp, idx, _ = geometry(mode, S, budget, stride)
+    g = torch.Generator(device=dev).manual_seed(99)
+    rnd = lambda h, n: torch.randn(L, h, n, D, generator=g, device=dev).half()
+    res = {}
+    for name, defer in (("deferred_scorer", True), ("immediate", False)):
+        bank = KVBank(L, Hq, H, D, cap=idx + stride, device=dev)
+        if streaming:
+            from easykv_amd.api import rope_tables
+            bank.set_rope(*rope_tables(idx + stride + 64, D))
+        bank.load_rows(rnd(H, idx), rnd(H, idx))
+        bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=g, device=dev), dim=-1).int()
+        bank.state_init(idx + stride, 2, stride)
+        plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=bp, recent=int(bp * 0.1), sink=4, stride=stride, streaming=streaming)
+        ins = [(rnd(Hq, stride), rnd(H, stride), rnd(H, stride)) for _ in range(2)]
+        out = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
+        views = [[(q[l:l + 1], k[l:l + 1], v[l:l + 1], out[l:l + 1]) for l in range(L)] for (q, k, v) in ins]
+        t0 = 0.0
+        for i in range(warm + n_steps):
+            if i == warm:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            for l in range(L):
+                q1, k1, v1, o1 = views[i % 2][l]
+                bank.attend(plan, q1, k1, v1, layer_begin=l, out=o1, defer=defer)
+            if defer:
+                bank.flush()
+        torch.cuda.synchronize(dev)
+        res[name] = (time.perf_counter() - t0) / n_steps / L * 1e6
+        del bank
+    by = algorithmic_bytes(H, Hq, D, idx + stride, stride, 3)
+    us = res["deferred_scorer"]
+    return {"workload": f"chunk step one layer per call: S={S} stride={stride} T={idx + stride} L={L} Hq={Hq} H={H} D={D} roco" + (", streaming=True" if streaming else ""),
+            "us_per_layer": us, "us_per_layer_immediate_scorer": res["immediate"], "value": stride / (us * L * 1e-6),
+            "unit": "prompt tokens/s (chunk phase, attention/eviction path only)",
+            "roofline_step": {"bound": "hbm (launch- / latency-bound in practice: 32 heads per launch)", "achieved": by["total"] / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": by["total"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bytes_per_layer_step": by["total"],
+                              "timing": "host wall clock over whole forwards / layers"}}
+
+
 def decode_run(args, dev, rank, world, scaling, DS, want_seq):
     """One timed Bench-D run.  scaling 'strong': the `--layers`-layer model is split over the ranks (this rank owns its
     LayerShard block); 'weak': every rank owns `--layers` layers."""
@@ -956,6 +1005,9 @@ def main():
                     live, live_src = live_pmc_step(sargs, os.path.join(ROOT, "tools", "bench_chunk.py"), env=env)
                     if live is not None:
                         spm["roofline"].update(traffic=live, traffic_source=live_src, traffic_over_algorithmic=live / spm["roofline"]["bytes_per_step"])
+            line["per_layer_chunk_steps"] = [per_layer_chunk_steps(args, dev, 4096, 8), per_layer_chunk_steps(args, dev, 4096, 64),
+                                             per_layer_chunk_steps(args, dev, 9994, 96),
+                                             per_layer_chunk_steps(args, dev, 10253, 96, n_steps=4, mode="ppl", budget=4096 / 10253, streaming=True, shape=(40, 40, 40))]
             line["dense_prefix"] = [dense_prefix(args, dev, 4096, 8), dense_prefix(args, dev, 9994, 96)]
             # scored prefix (keep_attention): BASELINE configs[2] (Mistral GQA, stride 16, budget 0.3: r_idx = 1216) and a 4906-token MHA prefix
             line["dense_prefix_scored"] = [dense_prefix_scored(args, dev, 1216, 8, 16, "configs[2]: S=4096 stride=16 budget=0.3"),

@@ -108,6 +108,7 @@ class BudgetedKVCache:
         self._cur = None
         self.score_prefix = False
         self.n_attend = 0        # attend() calls of the forward in flight (checked by the driver after every forward)
+        self.defer_chunk_scorer = True     # scored chunk steps of a layer-per-call model: one scorer launch per forward (round 4)
 
     def owns(self, layer_idx: int) -> bool:
         return self.layer_begin <= layer_idx < self.layer_begin + self.layer_count
@@ -146,6 +147,14 @@ class BudgetedKVCache:
             self._prefix_rule = (key, bool(info["two_pass"] and info["wide"]))
         return self._prefix_rule[1]
 
+    DEFER_WORKSPACE_LIMIT = 2 << 30      # bytes of logits / column sums of all layers a deferred chunk step may keep alive
+
+    def _defer_fits(self, plan, n) -> bool:
+        key = (plan.policy, plan.accumulate, plan.evict, plan.two_pass, type(self.bank).default_two_pass, self.streaming, n, self.bank.n_slots[0])
+        if getattr(self, "_defer_rule", (None, None))[0] != key:
+            self._defer_rule = (key, self.bank.deferred_workspace_bytes(plan, n) <= self.DEFER_WORKSPACE_LIMIT)
+        return self._defer_rule[1]
+
     def attend(self, layer_idx: int, q, k, v):
         """One layer of one forward: append + attention + score + select + compaction, all on device.
         ``layer_idx`` is the layer's index in the MODEL; it must lie in this cache's block."""
@@ -172,9 +181,13 @@ class BudgetedKVCache:
                                         v[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), layer_begin=layer_idx)
                 outs.append(o)
             return torch.cat(outs, dim=2)
-        if n == 1 and plan.phase == "decode" and self.layer_count > 1:
+        deferable_chunk = (n > 1 and plan.phase == "prefill" and plan.policy in ("roco", "h2o_head", "tova") and (plan.accumulate or plan.evict)
+                           and self.defer_chunk_scorer and self._defer_fits(plan, n))
+        if ((n == 1 and plan.phase == "decode") or deferable_chunk) and self.layer_count > 1:
             # one layer per call (a decoder stack): attention + fold of this layer now, the scorers of all owned layers in ONE
-            # launch after the last layer (KVBank.flush) — off the critical path of the stack
+            # launch after the last layer (KVBank.flush) — off the critical path of the stack.  Decode steps, and since round 4 the
+            # scored chunk steps of a strided prefill (their scorer launch — 32 workgroups, latency-bound, folds the key-range
+            # partials too — was more than half of a layer's time)
             out, _ = self.bank.attend(plan, q, k, v, layer_begin=layer_idx, defer=True)
             if self.n_attend == self.layer_count:
                 ids = self.bank.flush()

@@ -399,8 +399,8 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
       return EKV_E_ARG;
   }
   const int rep = bank->n_q_heads / bank->n_kv_heads;
-  if (st->defer_layers != 0) {   // deferred scorer: decode steps, explicit splits, attention + fold now / scorer later
-    if (st->defer_layers < 0 || st->defer_index < 0 || st->defer_index + st->layer_count > st->defer_layers || n != 1 || st->n_split <= 0 ||
+  if (st->defer_layers != 0) {   // deferred scorer: decode AND chunk steps (ABI 5), explicit splits, attention + fold now / scorer later
+    if (st->defer_layers < 0 || st->defer_index < 0 || st->defer_index + st->layer_count > st->defer_layers || st->n_split <= 0 ||
         (st->phases != (1 | 4) && st->phases != 8))
       return EKV_E_ARG;
   }
@@ -414,6 +414,10 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
     ws.partials += rows0 * ws.n_partials * (bank->head_dim + 2);
     ws.tova_row += (size_t)st->defer_index * ws.t_pad;
     if (ws.big_rows) ws.big_rows += (size_t)st->defer_index * bank->n_kv_heads * 3 * ws.t_pad;
+    // chunk steps: what the deferred scorer reads of the attention launches — column sums (two passes) or row statistics (one pass)
+    if (ws.stats) ws.stats += rows0 * ws.n_partials * 2;
+    if (ws.colsum) ws.colsum += (size_t)st->defer_index * bank->n_kv_heads * ws.n_col_parts * 2 * ws.t_pad;
+    if (ws.row_stats) ws.row_stats += rows0 * 2;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
 

@@ -250,15 +250,17 @@ class KVBank:
 
     # -- one layer per call (a real decoder stack): attention now, scoring / eviction once per token ------------------------
     def _attend_deferred(self, plan: StepPlan, q, k_new, v_new, layer, out):
-        """Decode step of ONE layer with the scorer deferred (ekv_step.defer_layers): attention + fold of this layer now — its
-        output is what the next layer waits for — and one scorer launch over all layers of the bank at :meth:`flush`, instead
-        of a 15 us latency-bound scorer kernel on the critical path of every layer."""
+        """Step of ONE layer with the scorer deferred (ekv_step.defer_layers): attention + fold of this layer now — its output is
+        what the next layer waits for — and one scorer launch over all layers of the bank at :meth:`flush`, instead of a
+        latency-bound scorer kernel of 32 workgroups on the critical path of every layer (decode: 15 us of a 25 us layer; a
+        96-row chunk step of the Llama2-7B shape: 66 us of a 124 us layer).  Decode steps and, since round 4, chunk steps."""
         d = self._defer
-        t = self.n_slots[layer] + 1
-        if d is None or d["plan"] is not plan or d["t"] != t:
+        n = q.shape[2]
+        t = self.n_slots[layer] + n
+        if d is None or d["plan"] is not plan or d["t"] != t or d["n"] != n:
             if d is not None and d["pending"]:
-                raise _lib.EkvError("attend(defer=True): the previous token step was not flushed")
-            st = self.make_step(plan, 1, 0, 1)
+                raise _lib.EkvError("attend(defer=True): the previous step was not flushed")
+            st = self.make_step(plan, n, 0, 1)
             if plan.n_split <= 0:      # the split count of a one-layer launch, fixed for both halves of the step
                 st.phases = 1
                 ns, fu = C.c_int32(0), C.c_int32(0)
@@ -270,11 +272,11 @@ class KVBank:
             st.layer_begin, st.layer_count, st.defer_index, st.phases = 0, self.n_layers, 0, 8
             check(self.lib.ekv_step_check(C.byref(self._bank), C.byref(st)), "ekv_step_check (deferred scorer)")
             need = self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st))
-            ids = torch.empty(self.n_layers, self.n_kv_heads, 1, dtype=torch.int32, device=self.device) if st.n_evict > 0 else None
+            ids = torch.empty(self.n_layers, self.n_kv_heads, st.n_evict, dtype=torch.int32, device=self.device) if st.n_evict > 0 else None
             ws = self._workspace(need)
             # everything that is the same for all layers of the token step is resolved once: the per-layer call below is on the
             # critical path of the decoder stack (host cost per layer ~ GPU cost per layer in this regime)
-            d = self._defer = dict(plan=plan, t=t, st=st, ws=ws, ids=ids, pending=0, rope=(_ptr(self.rope_cos), _ptr(self.rope_sin)),
+            d = self._defer = dict(plan=plan, t=t, n=n, st=st, ws=ws, ids=ids, pending=0, rope=(_ptr(self.rope_cos), _ptr(self.rope_sin)),
                                    st_ref=C.byref(st), bank_ref=C.byref(self._bank), ws_ptr=ws.data_ptr(), ws_len=ws.numel(),
                                    stream=self._stream(), call=self.lib.ekv_step_attend)
         st = d["st"]
@@ -283,7 +285,7 @@ class KVBank:
         ext = self.extent[layer]
         st.phys_extent = ext if ext > t else t
         if out is None:
-            out = torch.empty(1, self.n_q_heads, 1, self.head_dim, dtype=torch.float16, device=self.device)
+            out = torch.empty(1, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
         rc = d["call"](d["bank_ref"], d["st_ref"], q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(), out.data_ptr(), None,
                        d["rope"][0], d["rope"][1], d["ws_ptr"], d["ws_len"], d["stream"])
         if rc != 0:
@@ -291,6 +293,18 @@ class KVBank:
         self.extent[layer] = st.phys_extent
         d["pending"] += 1
         return out
+
+    def deferred_workspace_bytes(self, plan: StepPlan, q_len: int) -> int:
+        """Scratch a step of ``q_len`` queries needs when the scorers of all layers are deferred to :meth:`flush` (the logits / column
+        sums of every layer stay alive until then)."""
+        st = self.make_step(plan, q_len, 0, 1)
+        if plan.n_split <= 0:
+            st.phases = 1
+            ns, fu = C.c_int32(0), C.c_int32(0)
+            check(self.lib.ekv_step_plan(C.byref(self._bank), C.byref(st), C.byref(ns), C.byref(fu)), "ekv_step_plan")
+            st.n_split = ns.value
+        st.defer_layers, st.layer_begin, st.layer_count, st.defer_index, st.phases = self.n_layers, 0, self.n_layers, 0, 8
+        return int(self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st)))
 
     def flush(self):
         """Scorer of every layer of the token step opened by ``attend(..., defer=True)``: accumulate, select, compact — one
@@ -314,10 +328,10 @@ class KVBank:
     def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None, phases=0, overlap_scorer=False, defer=False):
         """q ``[layers, Hq, n, D]``, k_new/v_new ``[layers, H, n, D]`` (fp16, device).
         Returns (out ``[layers, Hq, n, D]`` fp16, evict_ids ``[layers, H, k]`` int32 or None).
-        ``defer=True`` (one layer, q_len 1): attention + fold only; the scorers of all layers run at :meth:`flush`."""
+        ``defer=True`` (one layer per call): attention + fold only; the scorers of all layers run at :meth:`flush`."""
         if defer:
-            if q.shape[0] != 1 or q.shape[2] != 1 or phases != 0:
-                raise ValueError("defer=True is for one-layer decode calls")
+            if q.shape[0] != 1 or phases != 0:
+                raise ValueError("defer=True is for one-layer calls")
             return self._attend_deferred(plan, q, k_new, v_new, layer_begin, out), None
         lc, _, n, _ = q.shape
         st = self.make_step(plan, n, layer_begin, lc)

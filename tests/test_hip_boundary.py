@@ -216,3 +216,56 @@ def test_deferred_scorer_per_layer_calls_equal_the_whole_step(policy, hq, h, str
     for a, b in zip(res["whole"][:4], res["deferred"][:4]):
         assert torch.equal(a, b)
     assert res["whole"][4] == res["deferred"][4]
+
+
+@pytest.mark.parametrize("policy,hq,h,d,stride,stream", [
+    ("roco", 4, 4, 128, 96, False),       # wide kernel, two passes (column sums deferred)
+    ("roco", 8, 2, 128, 16, False),       # GQA x4: 64 folded rows
+    ("h2o_head", 4, 4, 64, 8, False),     # 16x16 kernel, one pass (logits + row statistics deferred)
+    ("tova", 4, 4, 64, 8, False),         # tova: head-averaged last row
+    ("roco", 4, 4, 128, 48, True),        # RoPE-on-read, wide kernel
+    ("recency", 4, 4, 64, 8, False),      # range eviction
+])
+def test_deferred_scorer_chunk_steps_equal_the_whole_step(policy, hq, h, d, stride, stream):
+    """ABI 5: ekv_step.defer_layers for CHUNK steps — per layer the attention launches + fold (the output the next layer waits for),
+    ONE scorer launch over all layers at the end of the forward — equals the whole step of every layer bit for bit: outputs, evicted
+    ids, score rows, slot maps.  (One layer per call is what a decoder stack issues; the per-layer scorer launch was more than half
+    of a chunk step's time there.)"""
+    from easykv_amd import KVBank, StepPlan
+    from easykv_amd.api import rope_tables
+    L, t0, steps = 3, 1100, 4      # (T > 1024: one-layer calls of small strides stay off the logits-in-LDS kernel, whose arithmetic differs)
+    g = torch.Generator().manual_seed(hq * 10 + h + stride)
+    k0, v0 = torch.randn(L, h, t0, d, generator=g).half().cuda(), torch.randn(L, h, t0, d, generator=g).half().cuda()
+    qs = [torch.randn(L, hq, stride, d, generator=g).half().cuda() for _ in range(steps)]
+    ks = [torch.randn(L, h, stride, d, generator=g).half().cuda() for _ in range(steps)]
+    vs = [torch.randn(L, h, stride, d, generator=g).half().cuda() for _ in range(steps)]
+    res = {}
+    for mode in ("whole", "deferred"):
+        bank = KVBank(L, hq, h, d, cap=t0 + stride)
+        if stream:
+            bank.set_rope(*rope_tables(bank.cap + 8, d))
+        bank.load_rows(k0, v0)
+        bank.state_init(t0 + stride, 2, stride)
+        outs, idl = [], []
+        for i in range(steps):
+            plan = StepPlan(policy=policy, phase="prefill", evict=True, accumulate=policy != "recency", budget=t0 + stride, recent=40, sink=4,
+                            stride=stride, streaming=stream, tova_head_mean=policy == "tova", n_split=2,
+                            range_start=4 if policy == "recency" else -1)
+            out = torch.empty(L, hq, stride, d, dtype=torch.float16, device="cuda")
+            if mode == "whole":
+                ids = torch.full((L, h, stride), -1, dtype=torch.int32, device="cuda")
+                for l in range(L):
+                    bank.attend(plan, qs[i][l:l + 1], ks[i][l:l + 1], vs[i][l:l + 1], layer_begin=l, out=out[l:l + 1], evict_ids=ids[l:l + 1])
+            else:
+                for l in range(L):
+                    bank.attend(plan, qs[i][l:l + 1], ks[i][l:l + 1], vs[i][l:l + 1], layer_begin=l, out=out[l:l + 1], defer=True)
+                    assert bank.n_slots[l] == t0          # nothing is evicted before the flush
+                ids = bank.flush().clone()
+            assert bank.n_slots == [t0] * L
+            outs.append(out)
+            idl.append(torch.sort(ids, dim=-1)[0])
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(outs), torch.stack(idl), bank.slot_of_pos[:, :, :t0].clone(), bank.score_sum[:, :, :t0].clone(), list(bank.n_slots))
+    for a, b in zip(res["whole"][:4], res["deferred"][:4]):
+        assert torch.equal(a, b)
+    assert res["whole"][4] == res["deferred"][4]
