@@ -191,3 +191,18 @@ def test_config1_llama_prefill_stride8_full_geometry():
     assert len([e for e in tr.evictions if e["kind"] == "per_head"]) == 255      # (the first chunk only fills the cache up to idx)
     assert tr.cache_len == 2056 + 3
     assert res == " ".join(str(t) for t in tr.result)
+
+
+@pytest.mark.parametrize("policy,keep,hq,h,d,stride", [
+    ("roco", True, 8, 4, 64, 40),        # GQA x2: 80 folded rows; the scored prefix walks its query blocks inside one launch pair
+    ("h2o_head", False, 4, 4, 128, 96),  # 96 rows, head_dim 128
+    ("roco", True, 8, 2, 128, 12),       # GQA x4: 48 folded rows (the 2 x 2 wave shape)
+])
+def test_streaming_wide_strides_through_generate(policy, keep, hq, h, d, stride):
+    """Round 4: RoPE-on-read (streaming=True, easykv/llama_patch.py:310-327) at query blocks of 33..128 GQA-folded rows runs on the
+    wide-block kernel's RoPE variants — dense prefix, keep_attention prefix (one launch pair per layer), chunk steps with the scorers of
+    all layers deferred to one launch per forward — END TO END through ``easykv_amd.generate`` against the CPU oracle's ``generate``
+    (encoding mode, then plain decode): printed line, every bound eviction decision, outputs."""
+    cfg = dict(budget=0.5, kv_policy=policy, keep_attention=keep, streaming=True, max_new_tokens=3, temp_length=4, recent_ratio=0.1)
+    res, tr, frac = _run_pair("encoding", stride, cfg, 2, hq, h, d, 700, seed=100 + stride, min_stable=0.9)
+    assert res == " ".join(str(t) for t in tr.result)
