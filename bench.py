@@ -481,6 +481,51 @@ def boundary_kernels(args, dev, iters=6):
     return out
 
 
+def streaming_decode(args, dev, budget, policy):
+    """Secondary figure: the Bench-D decode step with ``streaming=True`` (RoPE-on-read, easykv/llama_patch.py:310-327: keys cached
+    un-rotated, rotated by their current position index on every read — fp32 tables, 512 table bytes per 256-byte key row from L2),
+    all layers in one fused launch, same steady-state preparation as the headline run."""
+    from easykv_amd import KVBank, StepPlan
+    from easykv_amd.api import rope_tables
+    L, Hq, D = args.layers, args.heads, args.head_dim
+    H = args.kv_heads or Hq
+    T = budget + 1
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    bank = KVBank(L, Hq, H, D, cap=T + 63, device=dev)
+    bank.set_rope(*rope_tables(T + 128, D))
+    bank.load_rows(torch.randn(L, H, budget, D, generator=gen, device=dev).half(), torch.randn(L, H, budget, D, generator=gen, device=dev).half())
+    bank.slot_of_pos[:, :, :budget] = torch.argsort(torch.rand(L, H, budget, generator=gen, device=dev), dim=-1).int()
+    bank.state_init(T, 0)
+    n_in = 32
+    qs = torch.randn(n_in, L, Hq, 1, D, generator=gen, device=dev).half()
+    ks = torch.randn(n_in, L, H, 1, D, generator=gen, device=dev).half()
+    vs = torch.randn(n_in, L, H, 1, D, generator=gen, device=dev).half()
+    o = torch.empty(L, Hq, 1, D, dtype=torch.float16, device=dev)
+    ids = torch.empty(L, H, 1, dtype=torch.int32, device=dev)
+    plan = StepPlan(policy=policy, phase="decode", evict=True, score_off=0, budget=budget, streaming=True)
+    n_split, fused = bank.step_plan(plan, 1)
+    t_end, i = time.perf_counter() + 0.3, 0
+    while time.perf_counter() < t_end:
+        for _ in range(32):
+            bank.attend(plan, qs[i % n_in], ks[i % n_in], vs[i % n_in], out=o, evict_ids=ids)
+            i += 1
+        torch.cuda.synchronize(dev)
+    n = 512
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for j in range(n):
+        bank.attend(plan, qs[(i + j) % n_in], ks[(i + j) % n_in], vs[(i + j) % n_in], out=o, evict_ids=ids)
+    ev[1].record()
+    torch.cuda.synchronize(dev)
+    t = ev[0].elapsed_time(ev[1]) / n * 1e-3
+    b = algorithmic_bytes(H, Hq, D, T, 1, {"roco": 3, "h2o_head": 1, "tova": 1}.get(policy, 0))
+    gbs = b["total"] * L / t / 1e9
+    return {"workload": f"bench-D decode step with streaming=True (RoPE-on-read): L={L} Hq={Hq} H={H} D={D} T={T} {policy}", "us_per_step": t * 1e6,
+            "value": 1.0 / t, "unit": "tokens/s", "plan": {"fused_one_launch": bool(fused), "n_split": n_split},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_step": b["total"] * L,
+                         "note": "algorithmic bytes exclude the rotation tables (L2-resident)"}}
+
+
 def stage_workloads(args, dev, budget, policy):
     """Secondary figures: what ONE RANK of the layer-sharded model runs per step at N = 2 / 4 / 8 (strong scaling) —
     the Bench-D decode step with 16 / 8 / 4 of the 32 layers in one launch — measured on this one GPU so that the first real 1/2/4/8
@@ -979,6 +1024,7 @@ def main():
                                      "score_select_us": t_score * 1e6}
         if world == 1 and not args.no_prefill and not args.graph and (args.layers, Hq, H, D) == (32, 32, 32, 128):
             line["stage_workloads"] = stage_workloads(args, dev, budget, args.policy)
+            line["streaming_decode"] = streaming_decode(args, dev, budget, args.policy)
         if world == 1 and not args.no_prefill and not args.graph:
             line["strided_prefill"] = strided_prefill(args, dev)
             sp = line["strided_prefill"]

@@ -1,4 +1,6 @@
 // head_dim / rope dispatch over the per-(D, rope) decode objects.
+#include <cstdlib>
+
 #include "ekv_common.h"
 #include "ekv_kernels.h"
 
@@ -41,7 +43,11 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 
 // The whole decode step in one launch: possible when a head is not split, at most one victim, and the row fits.
 // nw = 4: up to four workgroups per CU (LDS <= 80 KB keeps >= 2); nw = 8: one or two workgroups per CU.
-int ekv_decode_fused_nw(int n_heads_in_launch) { return (n_heads_in_launch >= 256 && n_heads_in_launch <= 512) ? 8 : 4; }
+int ekv_decode_fused_nw(int n_heads_in_launch) {
+  static const int force = [] { const char* e = std::getenv("EKV_FUSED_NW"); return e ? std::atoi(e) : 0; }();   // (A/B knob)
+  if (force == 4 || force == 8) return force;
+  return (n_heads_in_launch >= 256 && n_heads_in_launch <= 512) ? 8 : 4;
+}
 
 bool ekv_decode_fused_supported(int head_dim, int rep, int n_slots, int t_pad, int l_pad, int n_evict, int cap, int nw) {
   // (the slot map and the score rows are fetched 16 bytes at a time: rows must be 16-byte aligned)
