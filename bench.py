@@ -1053,6 +1053,7 @@ def main():
                         spm["roofline"].update(traffic=live, traffic_source=live_src, traffic_over_algorithmic=live / spm["roofline"]["bytes_per_step"])
             line["per_layer_chunk_steps"] = [per_layer_chunk_steps(args, dev, 4096, 8), per_layer_chunk_steps(args, dev, 4096, 64),
                                              per_layer_chunk_steps(args, dev, 9994, 96),
+                                             per_layer_chunk_steps(args, dev, 4096, 16, budget=0.3, shape=(32, 32, 8)),
                                              per_layer_chunk_steps(args, dev, 10253, 96, n_steps=4, mode="ppl", budget=4096 / 10253, streaming=True, shape=(40, 40, 40))]
             line["dense_prefix"] = [dense_prefix(args, dev, 4096, 8), dense_prefix(args, dev, 9994, 96)]
             # scored prefix (keep_attention): BASELINE configs[2] (Mistral GQA, stride 16, budget 0.3: r_idx = 1216) and a 4906-token MHA prefix
