@@ -280,7 +280,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
     off += ekv_align(rowsq * 2 * 4, 256);
   }
   w.q_rot = nullptr;
-  if (st->rope_on_read && st->q_len > 1) {
+  if (st->rope_on_read && st->q_len > 1 && !w.wide) {      // (16x16 kernel only: the wide-block kernel rotates Q in its prologue)
     w.q_rot = reinterpret_cast<__half*>(p + off);
     off += ekv_align(2 * rowsq * bank->head_dim * 2, 256);
   }

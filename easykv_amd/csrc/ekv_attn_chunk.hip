@@ -104,16 +104,17 @@ int ekv_chunk_col_parts(int qpw, bool rope) { (void)rope; return qpw == 4 ? 4 : 
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
                                  const EkvScoreArgs* fuse_sc) {
   if (two_pass && fuse_sc != nullptr) return hipErrorInvalidValue;
-  if (a.rope_cos != nullptr) {
-    if (a.q_rot_hi == nullptr || a.q_rot_lo == nullptr) return hipErrorInvalidValue;
-    const int n_rows = a.n_q_heads * a.q_len, rpb = 256 / (head_dim / 4);
-    hipLaunchKernelGGL(ekv_rope_q_kernel, dim3((n_rows + rpb - 1) / rpb, layer_count), dim3(256), 0, s, a, head_dim, n_rows);
-  }
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
   if (qb_rows != a.qb_rows || n_qblocks != a.n_qblocks) return hipErrorInvalidValue;
   const bool rope = a.rope_cos != nullptr;
-  if (ekv_chunk_wide(head_dim, a.n_q_heads / a.n_kv_heads, a.q_len, rope, two_pass, a.logits != nullptr)) {
+  const bool wide = ekv_chunk_wide(head_dim, a.n_q_heads / a.n_kv_heads, a.q_len, rope, two_pass, a.logits != nullptr);
+  if (rope && !wide) {      // (the wide-block kernel rotates its query rows itself, in the lane that holds them)
+    if (a.q_rot_hi == nullptr || a.q_rot_lo == nullptr) return hipErrorInvalidValue;
+    const int n_rows = a.n_q_heads * a.q_len, rpb = 256 / (head_dim / 4);
+    hipLaunchKernelGGL(ekv_rope_q_kernel, dim3((n_rows + rpb - 1) / rpb, layer_count), dim3(256), 0, s, a, head_dim, n_rows);
+  }
+  if (wide) {
     if (fuse_sc != nullptr || (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts < 1 || a.n_col_parts > n_qblocks))) return hipErrorInvalidValue;
     if (!two_pass && a.stats != nullptr) return hipErrorInvalidValue;      // (mode 0 writes row statistics whenever the array is there)
     const int nwq = qpw == 4 ? 4 : 2;
