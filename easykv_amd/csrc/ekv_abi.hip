@@ -279,6 +279,13 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
     w.row_stats = reinterpret_cast<float*>(p + off);
     off += ekv_align(rowsq * 2 * 4, 256);
   }
+  // deferred scorer of a layer-per-call model, wide two-pass chunk steps: the column-sum pass is deferred with it (one launch over
+  // all layers at the flush instead of a 256-workgroup launch per layer) — it needs every layer's raw queries
+  w.q_keep = nullptr;
+  if (st->defer_layers > 0 && st->q_len > 1 && w.wide && w.two_pass) {
+    w.q_keep = reinterpret_cast<__half*>(p + off);
+    off += ekv_align(rowsq * bank->head_dim * 2, 256);
+  }
   w.q_rot = nullptr;
   if (st->rope_on_read && st->q_len > 1 && !w.wide) {      // (16x16 kernel only: the wide-block kernel rotates Q in its prologue)
     w.q_rot = reinterpret_cast<__half*>(p + off);
@@ -418,6 +425,7 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
     if (ws.stats) ws.stats += rows0 * ws.n_partials * 2;
     if (ws.colsum) ws.colsum += (size_t)st->defer_index * bank->n_kv_heads * ws.n_col_parts * 2 * ws.t_pad;
     if (ws.row_stats) ws.row_stats += rows0 * 2;
+    if (ws.q_keep) ws.q_keep += rows0 * bank->head_dim;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -454,6 +462,7 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   aa.qb_rows = ws.qb_rows;
   aa.n_qblocks = ws.n_qblocks;
   aa.sm_div = st->sm_div;
+  aa.q_keep = ws.q_keep;
   aa.phys_extent = step_extent(bank, st);
   aa.l_pad = ekv_fused_logit_pad(bank, st, ws.t_pad);
 
@@ -554,7 +563,8 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   } else if (n == 1) {
     err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
   } else {
-    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, ws.two_pass != 0, s, fuse_chunk ? &sa : nullptr);
+    // (deferred wide two-pass step: only the one pass now — the column-sum pass runs with the scorer at the flush)
+    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, ws.two_pass != 0, s, fuse_chunk ? &sa : nullptr, ws.q_keep != nullptr ? 1 : 3);
   }
   if (err != hipSuccess) return EKV_E_LAUNCH;
   if (ph == 1 || fuse_chunk) return EKV_OK;
@@ -573,6 +583,15 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
       return launch_status();
     }
     return EKV_OK;
+  }
+  if ((ph & 8) && !(ph & 1) && n > 1 && ws.q_keep != nullptr) {
+    // the flush of a deferred chunk step: the column-sum pass of ALL layers (queries from the kept copies, the chunk's own rows from
+    // the cache slots the one pass of each layer wrote them to), then the scorer
+    EkvAttnArgs a2 = aa;
+    a2.q = ws.q_keep;
+    a2.q_keep = nullptr;
+    a2.new_in_cache = 1;
+    if (ekv_launch_attn_chunk(a2, bank->head_dim, st->layer_count, true, s, nullptr, 2) != hipSuccess) return EKV_E_LAUNCH;
   }
   sa.skip_fold = ((ph & 8) || ws.fold_in_kernel) ? 1 : 0;
   if (fast_scorer)   // decode steps: the fast scorer (same tail as the fused kernel)

@@ -102,7 +102,7 @@ int ekv_chunk_col_parts(int qpw, bool rope) { (void)rope; return qpw == 4 ? 4 : 
 
 // fuse_sc != nullptr: one-pass step with unsplit heads whose scorer runs as the tail of the attention kernel (no second launch)
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
-                                 const EkvScoreArgs* fuse_sc) {
+                                 const EkvScoreArgs* fuse_sc, int passes) {
   if (two_pass && fuse_sc != nullptr) return hipErrorInvalidValue;
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
@@ -121,8 +121,9 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
     // one pass over K and V (output, and for a scored step every row's softmax statistics), then — scored steps — the column-sum
     // pass over K
 #define EKW_GO(d, m) (rope ? ekv_launch_attn_wide_rope_d##d##_m##m(a, nwq, layer_count, s) : ekv_launch_attn_wide_d##d##_m##m(a, nwq, layer_count, s))
-    hipError_t e = head_dim == 128 ? EKW_GO(128, 0) : EKW_GO(64, 0);
-    if (two_pass && e == hipSuccess) e = head_dim == 128 ? EKW_GO(128, 2) : EKW_GO(64, 2);
+    hipError_t e = hipSuccess;
+    if (passes & 1) e = head_dim == 128 ? EKW_GO(128, 0) : EKW_GO(64, 0);
+    if (two_pass && (passes & 2) && e == hipSuccess) e = head_dim == 128 ? EKW_GO(128, 2) : EKW_GO(64, 2);
 #undef EKW_GO
     return e;
   }

@@ -19,6 +19,7 @@ struct EkvWs {
   int32_t fold_in_kernel;   // chunk step whose attention kernel writes the final output itself (no partials, no fold)
   int32_t wide;             // chunk step on the wide-query-block kernel (ekv_attn_wide.inc): ONE partial per split, ONE column-sum row
   int32_t fused_nw;     // waves per workgroup the fused decode kernel would use for this launch (4 or 8)
+  __half* q_keep;   // deferred wide two-pass chunk steps: [layer_count][Hq][q_len][D] raw queries kept for the flush's column-sum pass
   __half* q_rot;    // rope_on_read chunk steps: [2][layer_count][Hq][q_len][D] rotated queries, fp16 hi then lo
   int32_t t_pad, n_split, rows_per_split;
   int32_t n_partials;   // partials per query row the scorer folds (chunk kernels emit 2 per split)
@@ -53,6 +54,11 @@ struct EkvAttnArgs {
   uint32_t* arrive;            // split decode kernel: non-null = fold the key-range partials in the kernel (last-arriving split of a
                                //   head) and write the fp16 output to out_direct; the bank's counters [n_layers][H], 0 when idle
   float sm_div;
+  // deferred column-sum pass of the wide-block kernel (ekv_step.defer_layers, chunk steps): the one pass of a layer keeps its raw
+  // queries in q_keep ([layers][Hq][q_len][D], this call's slice); the column-sum pass at the flush reads them as `q` and takes the
+  // chunk's own K rows from the cache slots (new_in_cache) instead of k_new
+  __half* q_keep;
+  int32_t new_in_cache;
 };
 
 struct EkvScoreArgs {
@@ -80,8 +86,9 @@ struct EkvScoreArgs {
 EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* step, void* base);
 
 hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_count, hipStream_t s);
+// passes (wide-block kernel, two-pass scheme): bit 0 = the one pass (output + row statistics), bit 1 = the column-sum pass
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
-                                 const EkvScoreArgs* fuse_sc = nullptr);
+                                 const EkvScoreArgs* fuse_sc = nullptr, int passes = 3);
 size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs& a);
 bool ekv_score_rows_exceed_lds(int W, int rows);   // generic scorer: S / Q / C + keys of W columns do not fit 160 KB of LDS
 bool ekv_chunk_two_pass(int head_dim, int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode);

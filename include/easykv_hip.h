@@ -110,7 +110,8 @@ typedef struct ekv_step {
   int32_t defer_layers; /* > 0: DEFERRED SCORER for a model that issues one layer per call (a real decoder stack: layer l + 1's
                            query depends on layer l's output, easykv/easykv.py:264-269).  The attention output of a layer is
                            needed at once, its scoring / eviction only before the NEXT forward: the per-layer call (decode steps,
-                           and since ABI 5 chunk steps of any q_len; phases = 1|4: attention + fold) leaves its logits and partials in slice `defer_index` of a workspace laid
+                           and since ABI 5 chunk steps of any q_len; phases = 1|4: attention + fold — for two-pass steps of the
+                           wide-block kernel the column-sum pass is deferred as well and runs in the phases = 8 call) leaves its logits and partials in slice `defer_index` of a workspace laid
                            out for `defer_layers` layers, and ONE call with phases = 8 over all those layers
                            (layer_count = defer_layers, defer_index = 0) scores and evicts for the whole token.  Both calls must
                            pass the same explicit n_split and the same workspace.  0 = off.                               */
