@@ -12,18 +12,21 @@ from ._build import LIB
 
 # policy codes (include/easykv_hip.h)
 POLICY_NONE, POLICY_H2O_HEAD, POLICY_ROCO, POLICY_TOVA, POLICY_RANGE = 0, 1, 2, 3, 4
+PHASE_SLOT_TAIL_OK = 32
+PHASE_SLOT_ROWS = 16      # ekv_step.phases bit: the layers' score rows are in the slot-indexed layout (include/easykv_hip.h)
 POLICY_CODES = {"full": POLICY_NONE, "h2o_head": POLICY_H2O_HEAD, "roco": POLICY_ROCO, "tova": POLICY_TOVA,
                 "recency": POLICY_RANGE, "random": POLICY_RANGE}
 
 EXPORTS = ("ekv_abi_version", "ekv_strerror", "ekv_workspace_bytes", "ekv_step_plan", "ekv_bank_reset", "ekv_state_init",
-           "ekv_step_attend", "ekv_gather_ordered", "ekv_scatter_rows", "ekv_compact_inplace", "ekv_step_check", "ekv_step_info")
+           "ekv_step_attend", "ekv_gather_ordered", "ekv_scatter_rows", "ekv_compact_inplace", "ekv_step_check", "ekv_step_info",
+           "ekv_rows_to_slots", "ekv_rows_to_order")
 
 
 class Bank(C.Structure):
     _fields_ = [("k", C.c_void_p), ("v", C.c_void_p), ("slot_of_pos", C.c_void_p),
                 ("score_sum", C.c_void_p), ("score_sq", C.c_void_p), ("score_cnt", C.c_void_p),
                 ("n_layers", C.c_int32), ("n_q_heads", C.c_int32), ("n_kv_heads", C.c_int32),
-                ("head_dim", C.c_int32), ("cap", C.c_int32), ("arrive", C.c_void_p)]
+                ("head_dim", C.c_int32), ("cap", C.c_int32), ("arrive", C.c_void_p), ("birth", C.c_void_p), ("slot_state", C.c_void_p)]
 
 
 class Step(C.Structure):
@@ -67,9 +70,11 @@ def load():
     lib.ekv_compact_inplace.argtypes = [C.POINTER(Bank), i32, i32, i32, i32, vp, vp]
     lib.ekv_step_check.argtypes = [C.POINTER(Bank), C.POINTER(Step)]
     lib.ekv_step_info.argtypes = [C.POINTER(Bank), C.POINTER(Step), C.POINTER(C.c_int32), C.c_int32]
+    lib.ekv_rows_to_slots.argtypes = [C.POINTER(Bank), i32, i32, i32, vp]
+    lib.ekv_rows_to_order.argtypes = [C.POINTER(Bank), i32, i32, i32, vp]
     for name in EXPORTS[3:]:
         getattr(lib, name).restype = C.c_int
-    if lib.ekv_abi_version() != 5:
+    if lib.ekv_abi_version() != 6:
         raise EkvError("ABI version mismatch")
     _lib = lib
     return lib

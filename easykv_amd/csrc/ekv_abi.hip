@@ -149,6 +149,79 @@ __global__ void __launch_bounds__(256) ekv_range_evict_kernel(int32_t* slot_of_p
   for (int i = tid; i < k; i += 256) map[T - k + i] = s_vict[i];
 }
 
+// ---- ordered <-> slot-indexed score rows (ekv_decode_tail.h, "slot-indexed score rows") ------------------------------------------
+// One workgroup per (head, layer); everything is read into LDS before anything is written (the conversions are in place).
+// to_slots: entry j of the ordered rows (row = slot_of_pos[j]) becomes S[row], Q[row], C0[row] = C[j] (g = 0), birth[row] = j; the
+// next birth is n_slots.  Entries of the slot map below n_slots are dead afterwards; the free list [n_slots, cap) stays.
+__global__ void __launch_bounds__(256) ekv_rows_to_slots_kernel(const int32_t* slot_of_pos, float* S, float* Q, float* Cn, int32_t* birth,
+                                                                float* cnt_tail, float* slot_state, int n_kv_heads, int cap, int layer_begin, int T) {
+  extern __shared__ float s_rows[];      // [4][T]
+  const int h = blockIdx.x, ll = blockIdx.y, tid = threadIdx.x;
+  const size_t head = (size_t)(layer_begin + ll) * n_kv_heads + h, head_row = head * cap;
+  // the ordered count row's tail [T, cap) — what the next appended entries start from (zeros after decode steps, 0, -1, -2 ... after
+  // a strided chunk step) — has no place in a row-indexed array: parked, and put back by ekv_rows_to_order
+  for (int j = T + tid; j < cap; j += 256) cnt_tail[head_row + j] = Cn ? Cn[head_row + j] : 0.f;
+  for (int j = tid; j < T; j += 256) {
+    s_rows[j] = S[head_row + j];
+    s_rows[T + j] = Q ? Q[head_row + j] : 0.f;
+    s_rows[2 * T + j] = Cn ? Cn[head_row + j] : 0.f;
+    reinterpret_cast<int32_t*>(s_rows)[3 * T + j] = slot_of_pos[head_row + j];
+  }
+  __syncthreads();
+  for (int j = tid; j < T; j += 256) {
+    const int row = reinterpret_cast<const int32_t*>(s_rows)[3 * T + j];
+    S[head_row + row] = s_rows[j];
+    if (Q) Q[head_row + row] = s_rows[T + j];
+    if (Cn) Cn[head_row + row] = s_rows[2 * T + j];
+    birth[head_row + row] = j;
+  }
+  if (tid == 0) {
+    slot_state[2 * head] = 0.f;
+    reinterpret_cast<int32_t*>(slot_state)[2 * head + 1] = T;
+  }
+}
+
+// to_order: the live rows are the rows that are not on the free list [T, cap); the order index of a row is the rank of its birth
+// among them (counted: births are unique).  Rebuilds slot_of_pos[0, T), S / Q / C (C = C0 + g) in order, zero tails.
+__global__ void __launch_bounds__(256) ekv_rows_to_order_kernel(int32_t* slot_of_pos, float* S, float* Q, float* Cn, const int32_t* birth,
+                                                                const float* cnt_tail, const float* slot_state, int n_kv_heads, int cap, int layer_begin, int T) {
+  extern __shared__ float s_rows[];      // [4][cap]: S, Q, C0, birth (-1 = not live)
+  const int h = blockIdx.x, ll = blockIdx.y, tid = threadIdx.x;
+  const size_t head = (size_t)(layer_begin + ll) * n_kv_heads + h, head_row = head * cap;
+  int32_t* s_b = reinterpret_cast<int32_t*>(s_rows) + 3 * (size_t)cap;
+  const float g = slot_state[2 * head];
+  for (int r = tid; r < cap; r += 256) {
+    s_rows[r] = S[head_row + r];
+    s_rows[cap + r] = Q ? Q[head_row + r] : 0.f;
+    s_rows[2 * cap + r] = Cn ? Cn[head_row + r] : 0.f;
+    s_b[r] = birth[head_row + r];
+  }
+  __syncthreads();
+  for (int i = T + tid; i < cap; i += 256) s_b[slot_of_pos[head_row + i]] = -1;      // the free list: distinct rows
+  __syncthreads();
+  for (int r = tid; r < cap; r += 256) {
+    const int b = s_b[r];
+    if (b >= 0) {
+      int rank = 0;
+      for (int x = 0; x < cap; ++x) {
+        const int bx = s_b[x];
+        rank += (bx >= 0 && bx < b) ? 1 : 0;
+      }
+      slot_of_pos[head_row + rank] = r;
+      S[head_row + rank] = s_rows[r];
+      if (Q) Q[head_row + rank] = s_rows[cap + r];
+      if (Cn) Cn[head_row + rank] = s_rows[2 * cap + r] + g;
+    }
+  }
+  // tails: S / Q are zero behind the live entries in every flow; the count tail is the parked one (an evicting slot-layout step
+  // has zeroed its front entry, like the ordered step does)
+  for (int j = T + tid; j < cap; j += 256) {
+    S[head_row + j] = 0.f;
+    if (Q) Q[head_row + j] = 0.f;
+    if (Cn) Cn[head_row + j] = cnt_tail[head_row + j];
+  }
+}
+
 // A launch failure must be reported as THIS call's, not as whatever sticky-free error an earlier, unrelated runtime call of the
 // thread left behind: every entry point drops the stale last-error state first, then reads it back after its own launches.
 inline void drop_stale_error() { (void)hipGetLastError(); }
@@ -335,7 +408,7 @@ int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, in
   // as the tail of the attention kernel — asked of the dispatch itself (dry run); a step the dispatch would refuse plans as 0
   int32_t one = 0;
   if (step_attend_impl(bank, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true, &one) != EKV_OK) one = 0;
-  *fused = (one && st->phases == 0) ? 1 : 0;
+  *fused = (one && (st->phases & ~(EKV_PHASE_SLOT_ROWS | EKV_PHASE_SLOT_TAIL_OK)) == 0) ? 1 : 0;
   return EKV_OK;
 }
 
@@ -377,6 +450,26 @@ int ekv_state_init(const ekv_bank* bank, int32_t layer_begin, int32_t layer_coun
 
 }  // extern "C"
 
+// Which one-launch decode steps run on the slot-indexed layout: plain keys, a scored policy over the whole cache (score_off = 0), no
+// protected sink window (win_lo = 0: the recent tail is a birth threshold, a sink window would need ranks), at most one victim,
+// GQA factor <= 4 and an extent of at most 9 (4-wave workgroups) / 5 (8-wave) rows per thread — the builds whose thread-owned
+// columns stay in registers without spills.
+// second half of ekv_bank.birth: the parked tail of the ordered count row (float), same [layer][head][cap] indexing
+static float* ekv_cnt_tail(const ekv_bank* bank) {
+  return reinterpret_cast<float*>(bank->birth + (size_t)bank->n_layers * bank->n_kv_heads * bank->cap);
+}
+
+static bool ekv_slot_rows_supported_impl(const ekv_bank* bank, const ekv_step* st, int phys_extent, int fused_nw, int t_pad) {
+  const bool scored = st->policy == EKV_POLICY_H2O_HEAD || st->policy == EKV_POLICY_ROCO || st->policy == EKV_POLICY_TOVA;
+  const int rep = bank->n_q_heads / bank->n_kv_heads;
+  if (!bank->birth || !bank->slot_state || !scored || st->q_len != 1 || st->rope_on_read || st->n_evict > 1) return false;
+  if (st->score_off != 0 || st->win_lo != 0 || st->tova_head_mean || rep > 4 || !st->accumulate) return false;
+  if (st->count_add != (float)(int)st->count_add) return false;      // counts stay exact integers (count = base + running sum)
+  const int max_rows = fused_nw == 8 ? 512 * 5 : 256 * 9;
+  if (phys_extent > max_rows || bank->cap > 9600) return false;      // (cap: ekv_rows_to_order stages four rows of `cap` words in LDS)
+  return 2 * ekv_align((size_t)phys_extent, 256) <= 3 * ekv_align((size_t)t_pad, 256);      // (LDS: two rows over [0, E) instead of three over [0, T))
+}
+
 // Body of ekv_step_attend.  `dry` (ekv_step_check): every argument / shape / capability test of the real call, in the same
 // order, and a return right before the first launch — nothing is launched, no pointer is dereferenced, the workspace is not
 // needed.
@@ -386,6 +479,13 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   if (one_launch) *one_launch = 0;
   if (int e = check_bank(bank)) return e;
   if (!st) return EKV_E_ARG;
+  // EKV_PHASE_SLOT_ROWS: the bank's score rows are in the slot-indexed layout (ekv_rows_to_slots) — only the one-launch decode step
+  // runs on it; everything below sees the remaining phase bits
+  const bool slot_rows = (st->phases & EKV_PHASE_SLOT_ROWS) != 0;
+  const bool slot_tail_ok = slot_rows && (st->phases & EKV_PHASE_SLOT_TAIL_OK) != 0;
+  ekv_step st_plain = *st;
+  st_plain.phases &= ~(EKV_PHASE_SLOT_ROWS | EKV_PHASE_SLOT_TAIL_OK);
+  st = &st_plain;
   if (!dry && (!q || !k_new || !v_new || !out || !workspace)) return EKV_E_ARG;
   if (int e = check_layers(bank, st->layer_begin, st->layer_count)) return e;
   const int T = st->n_slots, n = st->q_len;
@@ -509,10 +609,18 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // whole decode step in one launch when no head has to be split
   if (n == 1 && st->phases == 0 && ws.n_split == 1 &&
       ekv_decode_fused_supported(bank->head_dim, rep, T, ws.t_pad, aa.l_pad, st->n_evict, bank->cap, ws.fused_nw)) {
+    if (slot_rows) {
+      if (!ekv_slot_rows_supported_impl(bank, st, aa.phys_extent, ws.fused_nw, ws.t_pad)) return EKV_E_UNSUPPORTED;
+      sa.birth = bank->birth;
+      sa.slot_state = bank->slot_state;
+      sa.cnt_tail = ekv_cnt_tail(bank);
+      sa.slot_tail_ok = slot_tail_ok ? 1 : 0;
+    }
     if (one_launch) *one_launch = 1;
     if (dry) return EKV_OK;
     return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, ws.fused_nw, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
+  if (slot_rows) return EKV_E_UNSUPPORTED;      // every other kernel reads the ordered layout: ekv_rows_to_order first
 
   // small-row chunk step (configs[1]: stride 8): one launch, logits in LDS, K and V read once
   if (n > 1 && ekv_chunk_lds_supported(bank, st, aa.phys_extent, scored) &&
@@ -644,6 +752,34 @@ int ekv_scatter_rows(const ekv_bank* bank, int32_t layer_begin, int32_t layer_co
                      const_cast<__half*>(static_cast<const __half*>(k_in)),
                      const_cast<__half*>(static_cast<const __half*>(v_in)), bank->n_kv_heads, bank->cap, bank->head_dim,
                      layer_begin, pos_begin, n);
+  return launch_status();
+}
+
+int ekv_rows_to_slots(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void* stream) {
+  if (int e = check_bank(bank)) return e;
+  if (int e = check_layers(bank, layer_begin, layer_count)) return e;
+  if (!bank->score_sum || !bank->birth || !bank->slot_state || n_slots < 0 || n_slots > bank->cap) return EKV_E_ARG;
+  const size_t lds = (size_t)4 * n_slots * 4;
+  if (lds > 150 * 1024) return EKV_E_UNSUPPORTED;
+  drop_stale_error();
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ekv_rows_to_slots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ekv_rows_to_slots_kernel, dim3(bank->n_kv_heads, layer_count), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     bank->slot_of_pos, bank->score_sum, bank->score_sq, bank->score_cnt, bank->birth, ekv_cnt_tail(bank), bank->slot_state,
+                     bank->n_kv_heads, bank->cap, layer_begin, n_slots);
+  return launch_status();
+}
+
+int ekv_rows_to_order(const ekv_bank* bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void* stream) {
+  if (int e = check_bank(bank)) return e;
+  if (int e = check_layers(bank, layer_begin, layer_count)) return e;
+  if (!bank->score_sum || !bank->birth || !bank->slot_state || n_slots < 0 || n_slots > bank->cap) return EKV_E_ARG;
+  const size_t lds = (size_t)4 * bank->cap * 4;
+  if (lds > 150 * 1024) return EKV_E_UNSUPPORTED;
+  drop_stale_error();
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ekv_rows_to_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ekv_rows_to_order_kernel, dim3(bank->n_kv_heads, layer_count), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     bank->slot_of_pos, bank->score_sum, bank->score_sq, bank->score_cnt, bank->birth, ekv_cnt_tail(bank), bank->slot_state,
+                     bank->n_kv_heads, bank->cap, layer_begin, n_slots);
   return launch_status();
 }
 

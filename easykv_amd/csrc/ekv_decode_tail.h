@@ -100,22 +100,22 @@ using Red4 = RedN<4>;
 // issue the DMA early and keep these loads (whose LDS stores wait for them) out of the way of its own first loads.
 template <int NW = 4>
 __device__ __forceinline__ void ekv_tail_prefetch_ragged(const EkvScoreArgs& sc, size_t head_row, int W, bool roco, float* sS,
-                                                         float* sQ, float* sC) {
+                                                         float* sQ, float* sC, bool with_cnt = true) {
   const int tid = threadIdx.x;
   for (int j = W / 256 * 256 + tid; j < W; j += 64 * NW) {
     sS[j] = sc.score_sum[head_row + j];
     if (roco) {
       sQ[j] = sc.score_sq[head_row + j];
-      sC[j] = sc.score_cnt[head_row + j];
+      if (with_cnt) sC[j] = sc.score_cnt[head_row + j];
     }
   }
 }
 
 template <int NW = 4, bool RAGGED = true>
 __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, size_t head_row, int W, int w_pad, bool roco,
-                                                       float* sS, float* sQ, float* sC) {
+                                                       float* sS, float* sQ, float* sC, bool with_cnt = true) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_arr = roco ? 3 : 1;
+  const int n_arr = roco ? (with_cnt ? 3 : 2) : 1;
   const int full = W / 256;
   for (int c = wave; c < full * n_arr; c += NW) {
     const int arr = c / full, ch = c % full;
@@ -123,7 +123,7 @@ __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, s
     float* dst = sS + (size_t)arr * w_pad + ch * 256;     // wave-uniform base; lane i lands at +16*i bytes
     __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
-  if (RAGGED) ekv_tail_prefetch_ragged<NW>(sc, head_row, W, roco, sS, sQ, sC);
+  if (RAGGED) ekv_tail_prefetch_ragged<NW>(sc, head_row, W, roco, sS, sQ, sC, with_cnt);
 }
 
 // PHYS: s_logit is indexed by PHYSICAL row (the fused kernel streamed the rows in address order); the logit of position
@@ -447,5 +447,267 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
         if (p < T) map[p == pv ? T - 1 : p - 1] = moved[it];
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Slot-indexed score rows (ekv_step.phases & EKV_PHASE_SLOT_ROWS; fused decode step, plain keys, at most one victim).
+//
+// In the ordered layout above the score rows and the slot map are indexed by ORDER (age rank): an eviction shifts every entry
+// behind the victim, so a decode step rewrites S, Q, C and half the slot map — 28 KB per head and step next to 24 KB read — and
+// written bytes cost about twice what read bytes do in the middle of a read stream (measured, ekv_chunk_lds.inc).  Here the rows
+// are indexed by PHYSICAL row, like K / V and like the logits the stream leaves in LDS:
+//   S[row], Q[row]      accumulated scores (easykv/easykv.py:287-300), rewritten every step (they change)
+//   C0[row]             count base, written once when the row is (re)used: count = C0[row] + g, g = the head's running sum of
+//                       count_add (easykv.py:304 adds the same number to every entry: exact while counts are integers < 2^24)
+//   birth[row]          order key, written once: the age rank of the ordered layout is the rank of `birth` among the live rows
+//   state[head]         (g, next birth)
+// An eviction moves nothing: the victim's row goes to the front of the free list (slot_of_pos[T - 1], one word) and its S / Q / C0 /
+// birth die with it.  Ties go to the lower birth = the lower order index (same decisions as the ordered layout); windows that the
+// ordered layout states as index ranges — the newest `tail` entries — are birth thresholds, exact by a counting check with a
+// bisection fallback.  ekv_rows_to_slots / ekv_rows_to_order convert between the layouts (ekv_abi.hip).
+// Thread t owns rows t, t + NT, ...: every pass touches its own columns only, so the passes need no barrier between them.
+// S / Q are staged in LDS by LDS-DMA under the stream (like the ordered layout's rows); C0 and birth come straight into registers
+// (`cB`, `cC`: loads issued by the caller when its stream ends, consumed after the softmax passes) — a third and fourth LDS row
+// would cost the fourth workgroup per CU.
+template <int REP, int ITEMS, int NW>
+__device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int ll, int h, size_t head_row, int T, int E,
+                                                     float* s_logit, int l_pad, float* sS, float* sQ, const float (&cC)[ITEMS],
+                                                     const int32_t (&cB)[ITEMS], RedN<NW>& red, uint32_t* s_hist,
+                                                     unsigned long long* s_list, int list_cap, const float* part_max, int n_part,
+                                                     int part_stride, const uint32_t* s_deadw, int new_row, float g_old, float c_new,
+                                                     int nb) {
+  const int tid = threadIdx.x;
+  constexpr int NT = 64 * NW;
+  const bool roco = sc.policy == EKV_POLICY_ROCO;
+  const float g_new = g_old + sc.count_add;
+  // this thread's rows: j = tid + it * NT; bit `it` of livem = the row holds a live entry (the appended row included)
+  unsigned livem = 0;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int j = tid + it * NT;
+    const bool lv = j < E && (j == new_row || !((s_deadw[j >> 5] >> (j & 31)) & 1u));
+    livem |= (lv ? 1u : 0u) << it;
+  }
+  auto lives = [&](int it) { return (livem >> it) & 1u; };
+  // ---- exact softmax over the live rows, GQA fold, accumulate (easykv/easykv.py:271-300); S / Q go back to HBM right away ----
+  if (sc.accumulate) {
+    float mx[REP], sm[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) mx[r] = EKV_NEG_INF, sm[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < REP; ++r)
+      for (int i = 0; i < n_part; ++i) mx[r] = fmaxf(mx[r], part_max[(size_t)(i * REP + r) * part_stride]);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * NT;
+      if (j < E) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+          const float e = lives(it) ? expf(s_logit[(size_t)r * l_pad + j] - mx[r]) : 0.f;
+          s_logit[(size_t)r * l_pad + j] = e;
+          sm[r] += e;
+        }
+      }
+    }
+    red.template sum_n<REP>(sm);
+    float inv_sm[REP];
+#pragma unroll
+    for (int r = 0; r < REP; ++r) inv_sm[r] = 1.f / sm[r];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * NT;
+      if (lives(it)) {
+        float pb = 0.f;
+#pragma unroll
+        for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * l_pad + j] * inv_sm[r];
+        if (REP > 1) pb = pb / (float)REP;
+        const bool fresh = j == new_row || sc.policy == EKV_POLICY_TOVA;
+        const float s_new = fresh ? pb : sS[j] + pb;
+        sS[j] = s_new;
+        sc.score_sum[head_row + j] = s_new;
+        if (roco) {
+          const float q_new = j == new_row ? pb * pb : sQ[j] + pb * pb;
+          sQ[j] = q_new;
+          sc.score_sq[head_row + j] = q_new;
+        }
+      }
+    }
+  }
+  const size_t head = (size_t)(sc.layer_begin + ll) * sc.n_kv_heads + h;
+  if (tid == 0) {      // the appended row's count base (c_new: what the ordered row holds behind its live entries, minus g) and birth
+    sc.score_cnt[head_row + new_row] = c_new;
+    sc.birth[head_row + new_row] = nb;
+    sc.slot_state[2 * head] = g_new;
+    reinterpret_cast<int32_t*>(sc.slot_state)[2 * head + 1] = nb + 1;
+  }
+  if (sc.n_evict != 1) return;
+
+  // count base and birth of this thread's rows (the caller's loads are first waited for HERE, behind the softmax passes)
+  float rC[ITEMS];
+  int32_t rB[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int j = tid + it * NT;
+    rC[it] = j == new_row ? c_new : cC[it];      // (a recycled row still holds its last owner's count base and birth)
+    rB[it] = j == new_row ? nb : cB[it];
+  }
+  // ---- the newest `tail` entries are protected: birth > nb - tail when none of them was ever evicted (counting check) ----
+  const int tail = roco ? sc.roco_tail : sc.win_tail;
+  int b_prot = nb - tail;                       // protected <=> birth > b_prot
+  if (tail > 0 && !sc.slot_tail_ok) {           // (slot_tail_ok: the caller vouches for it — EKV_PHASE_SLOT_TAIL_OK — and the check's reduction is saved)
+    int c = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) c += (lives(it) && rB[it] > b_prot) ? 1 : 0;
+    if (red.sum_int(c) != min(tail, T)) {       // rare (the window grew since those entries were appended): exact threshold by bisection
+      int lo = -1, hi = nb;                     // largest b with #{birth > b} >= min(tail, T)
+      while (lo < hi) {
+        const int mid = lo + (hi - lo + 1) / 2;
+        int c2 = 0;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) c2 += (lives(it) && rB[it] > mid) ? 1 : 0;
+        if (red.sum_int(c2) >= min(tail, T)) lo = mid; else hi = mid - 1;
+      }
+      b_prot = lo;
+    }
+  }
+  unsigned long long best = ~0ull;              // (order-preserving key of the victim criterion) << 32 | birth
+  if (roco) {
+    const uint32_t kSent = ekv_fkey(1e9f);
+    uint32_t kstd[ITEMS];                       // std keys; rows that are not live rank after everything (composite ~0)
+    auto comp = [&](int it) { return lives(it) ? (((unsigned long long)kstd[it] << 32) | (uint32_t)rB[it]) : ~0ull; };
+    uint32_t kmin = ~0u, nmax = ~0u;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * NT;
+      uint32_t key = ~0u;
+      if (lives(it)) {
+        const float c = rC[it] + g_new;
+        rC[it] = c;
+        const float mean = sS[j] / c;
+        float sd = sqrtf(sQ[j] / c - mean * mean);
+        if (rB[it] > b_prot) sd = 1e9f;
+        key = ekv_fkey(sd);
+        if (key < kSent) {
+          kmin = min(kmin, key);
+          nmax = min(nmax, ~key);
+        }
+      }
+      kstd[it] = key;
+    }
+    if (tid < 256) s_hist[tid] = 0;
+    if (tid < 8) s_hist[256 + tid] = 0;
+    red.min2_u32(kmin, nmax);
+    const uint32_t kmax = ~nmax;
+    unsigned long long thr = 0;
+    if (kmin <= kmax) {
+      const uint32_t range = kmax - kmin;
+      const int shift = range < 256u ? 0 : 24 - __clz(range);
+      auto bin_of = [&](uint32_t k) { return k >= kSent ? 255u : min(255u, (k - kmin) >> shift); };
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it)
+        if (lives(it)) atomicAdd(&s_hist[bin_of(kstd[it])], 1u);
+      __syncthreads();
+      if (tid < 64) {
+        const uint32_t c0 = s_hist[4 * tid], c1 = s_hist[4 * tid + 1], c2 = s_hist[4 * tid + 2], c3 = s_hist[4 * tid + 3];
+        uint32_t incl = c0 + c1 + c2 + c3;
+        const uint32_t mine = incl;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+          if (tid >= o) incl += up;
+        }
+        const uint32_t excl = incl - mine, k1 = (uint32_t)sc.roco_k1;
+        if (excl < k1 && k1 <= incl) {
+          uint32_t below = excl, b = 4 * tid;
+          if (below + c0 < k1) { below += c0; ++b;
+            if (below + c1 < k1) { below += c1; ++b;
+              if (below + c2 < k1) { below += c2; ++b; } } }
+          s_hist[257] = b;
+          s_hist[258] = below;
+        }
+      }
+      __syncthreads();
+      const uint32_t b_sel = s_hist[257], below = s_hist[258], in_bin = s_hist[b_sel];
+      if ((int)in_bin <= list_cap && (int)in_bin <= NT) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+          if (lives(it) && bin_of(kstd[it]) == b_sel) s_list[atomicAdd(&s_hist[256], 1u)] = comp(it);
+        __syncthreads();
+        if (tid < (int)in_bin) {
+          const unsigned long long e = s_list[tid];
+          uint32_t rank = 0;
+          for (int i = 0; i < (int)in_bin; ++i) rank += s_list[i] < e ? 1u : 0u;
+          if (below + rank == (uint32_t)sc.roco_k1 - 1u) *reinterpret_cast<unsigned long long*>(s_hist + 260) = e + 1ull;
+        }
+        __syncthreads();
+        thr = *reinterpret_cast<const unsigned long long*>(s_hist + 260);
+      }
+    }
+    if (thr == 0) {      // fallback: bitwise bisection on the keys, ties at the threshold to the lower births
+      uint32_t tau = 0;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t t = tau | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) c += (lives(it) && kstd[it] < t) ? 1 : 0;
+        if (red.sum_int(c) < sc.roco_k1) tau = t;
+      }
+      int c_less = 0, c_eq = 0;
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        c_less += (lives(it) && kstd[it] < tau) ? 1 : 0;
+        c_eq += (lives(it) && kstd[it] == tau) ? 1 : 0;
+      }
+      const int need = sc.roco_k1 - red.sum_int(c_less);
+      long long bound = (long long)nb + 1;      // exclusive bound on the birth of the tied keys that still belong to F
+      if (red.sum_int(c_eq) != need) {
+        long long lo = 0, hi = (long long)nb + 1;
+        while (lo < hi) {
+          const long long mid = (lo + hi) >> 1;
+          int c = 0;
+#pragma unroll
+          for (int it = 0; it < ITEMS; ++it) c += (lives(it) && kstd[it] == tau && (long long)rB[it] < mid) ? 1 : 0;
+          if (red.sum_int(c) >= need) hi = mid; else lo = mid + 1;
+        }
+        bound = lo;
+      }
+      thr = ((unsigned long long)tau << 32) | (uint32_t)bound;
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * NT;
+      if (lives(it) && comp(it) < thr) {
+        const unsigned long long x = ((unsigned long long)ekv_fkey(sS[j] / rC[it]) << 32) | (uint32_t)rB[it];
+        best = x < best ? x : best;
+      }
+    }
+  } else {             // h2o_head / tova: argmin of the accumulated score outside the protected tail (win_lo == 0 in this layout)
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * NT;
+      if (lives(it) && rB[it] <= b_prot) {
+        const unsigned long long x = ((unsigned long long)ekv_fkey(sS[j]) << 32) | (uint32_t)rB[it];
+        best = x < best ? x : best;
+      }
+    }
+  }
+  best = red.min_u64(best);
+  // the victim's row: births are unique, its owner publishes the row; its order index (what the reference reports) = the number of
+  // live rows born before it
+  const int b_v = (int)(best & 0xFFFFFFFFu);
+  int n_before = 0;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if (lives(it)) {
+      if (rB[it] == b_v) s_hist[262] = (uint32_t)(tid + it * NT);
+      n_before += rB[it] < b_v ? 1 : 0;
+    }
+  }
+  if (sc.evict_ids != nullptr) n_before = red.sum_int(n_before); else __syncthreads();
+  if (tid == 0) {
+    if (sc.evict_ids != nullptr) sc.evict_ids[(size_t)ll * sc.n_kv_heads + h] = n_before;
+    sc.slot_of_pos[head_row + T - 1] = (int32_t)s_hist[262];     // front of the free list: the next append recycles the victim's row
+    sc.cnt_tail[head_row + T - 1] = 0.f;                         // (the ordered step leaves a zero count behind the live entries)
   }
 }

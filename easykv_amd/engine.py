@@ -59,10 +59,18 @@ class KVBank:
         self.n_layers, self.n_q_heads, self.n_kv_heads, self.head_dim, self.cap = n_layers, n_q_heads, n_kv_heads, head_dim, cap
         self.k = torch.empty(n_layers, n_kv_heads, cap, head_dim, dtype=torch.float16, device=dev)
         self.v = torch.empty_like(self.k)
-        self.slot_of_pos = torch.empty(n_layers, n_kv_heads, cap, dtype=torch.int32, device=dev)
-        self.score_sum = torch.zeros(n_layers, n_kv_heads, cap, dtype=torch.float32, device=dev) if scored else None
-        self.score_sq = torch.zeros_like(self.score_sum) if scored else None
-        self.score_cnt = torch.zeros_like(self.score_sum) if scored else None
+        # (the state tensors are reached through properties: reading one converts slot-indexed layers back to the ordered layout)
+        self._slot_of_pos = torch.empty(n_layers, n_kv_heads, cap, dtype=torch.int32, device=dev)
+        self._score_sum = torch.zeros(n_layers, n_kv_heads, cap, dtype=torch.float32, device=dev) if scored else None
+        self._score_sq = torch.zeros_like(self._score_sum) if scored else None
+        self._score_cnt = torch.zeros_like(self._score_sum) if scored else None
+        # slot-indexed score rows (include/easykv_hip.h, EKV_PHASE_SLOT_ROWS): order keys, (count offset, next birth) per head, and
+        # which layers currently hold that layout
+        self.birth = torch.zeros(2, n_layers, n_kv_heads, cap, dtype=torch.int32, device=dev) if scored else None
+        self.slot_state = torch.zeros(n_layers, n_kv_heads, 2, dtype=torch.float32, device=dev) if scored else None
+        self._slot_rows = [False] * n_layers
+        self._slot_min_tail = [1 << 30] * n_layers      # smallest protected tail of an evicting step since the conversion
+        self._slot_ok = {}        # step shape -> does the slot-indexed decode kernel take it (ekv_step_check)
         self.n_slots = [0] * n_layers
         # High-water mark of live rows per layer.  The library keeps the free list as [freed rows (most recent first), never-
         # used rows ascending] and appends take from its front, so every live row has a physical index < extent: the
@@ -78,12 +86,79 @@ class KVBank:
         self._score_done = [None] * n_layers
         self._defer = None      # deferred-scorer state of the token step in flight (attend(..., defer=True) ... flush())
         self.arrive = torch.zeros(n_layers, n_kv_heads, dtype=torch.int32, device=dev)     # arrival counters of the in-kernel fold
-        self._bank = Bank(self.k.data_ptr(), self.v.data_ptr(), self.slot_of_pos.data_ptr(),
-                          self.score_sum.data_ptr() if scored else None, self.score_sq.data_ptr() if scored else None,
-                          self.score_cnt.data_ptr() if scored else None, n_layers, n_q_heads, n_kv_heads, head_dim, cap,
-                          self.arrive.data_ptr())
+        self._bank = Bank(self.k.data_ptr(), self.v.data_ptr(), self._slot_of_pos.data_ptr(),
+                          self._score_sum.data_ptr() if scored else None, self._score_sq.data_ptr() if scored else None,
+                          self._score_cnt.data_ptr() if scored else None, n_layers, n_q_heads, n_kv_heads, head_dim, cap,
+                          self.arrive.data_ptr(), self.birth.data_ptr() if scored else None,
+                          self.slot_state.data_ptr() if scored else None)
         self.rope_cos = self.rope_sin = None
         self.reset()
+
+    # -- layout of the score rows -------------------------------------------------------------------
+    use_slot_rows = True      # one-launch decode steps run on the slot-indexed layout where the library supports it
+
+    def _ensure_ordered(self, layer_begin=0, layer_count=None):
+        """Bring the score rows / slot map of the layers back to the ordered layout (every kernel but the one-launch decode step
+        reads that one; so do the state tensors handed out below)."""
+        end = self.n_layers if layer_count is None else layer_begin + layer_count
+        l = layer_begin
+        while l < end:
+            if not self._slot_rows[l]:
+                l += 1
+                continue
+            m = l
+            while m < end and self._slot_rows[m] and self.n_slots[m] == self.n_slots[l]:
+                m += 1
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.EkvError("a layout change of the score rows cannot be captured in a graph: run the step once outside the capture")
+            check(self.lib.ekv_rows_to_order(C.byref(self._bank), l, m - l, self.n_slots[l], self._stream()), "ekv_rows_to_order")
+            for i in range(l, m):
+                self._slot_rows[i] = False
+            l = m
+
+    def _enter_slot_rows(self, st) -> bool:
+        """Decide whether this one-launch decode step runs on the slot-indexed layout, converting its layers if it does."""
+        lb, lc = st.layer_begin, st.layer_count
+        rows = self._slot_rows[lb:lb + lc]
+        if not (self.use_slot_rows and self._score_sum is not None) or len(set(self.n_slots[lb:lb + lc])) != 1:
+            return False
+        st.phases = _lib.PHASE_SLOT_ROWS
+        key = bytes(st)
+        ok = self._slot_ok.get(key)
+        if ok is None:
+            ok = self._slot_ok[key] = self.lib.ekv_step_check(C.byref(self._bank), C.byref(st)) == 0
+        st.phases = 0
+        if not ok:
+            return False
+        if not all(rows):
+            if torch.cuda.is_current_stream_capturing():
+                return False          # (no layout change inside a capture: this step runs on the ordered layout)
+            self._ensure_ordered(lb, lc)     # (a partly converted range)
+            check(self.lib.ekv_rows_to_slots(C.byref(self._bank), lb, lc, self.n_slots[lb], self._stream()), "ekv_rows_to_slots")
+            for i in range(lb, lb + lc):
+                self._slot_rows[i] = True
+                self._slot_min_tail[i] = 1 << 30      # (births = order indices: every tail is consecutive)
+        return True
+
+    @property
+    def slot_of_pos(self):
+        self._ensure_ordered()
+        return self._slot_of_pos
+
+    @property
+    def score_sum(self):
+        self._ensure_ordered()
+        return self._score_sum
+
+    @property
+    def score_sq(self):
+        self._ensure_ordered()
+        return self._score_sq
+
+    @property
+    def score_cnt(self):
+        self._ensure_ordered()
+        return self._score_cnt
 
     # -- plumbing -----------------------------------------------------------------------------
     def _stream(self):
@@ -98,6 +173,8 @@ class KVBank:
         check(self.lib.ekv_bank_reset(C.byref(self._bank), self._stream()), "ekv_bank_reset")
         self.n_slots = [0] * self.n_layers
         self.extent = [0] * self.n_layers
+        self._slot_rows = [False] * self.n_layers
+        self._slot_min_tail = [1 << 30] * self.n_layers
         self._defer = None      # (a half-open deferred token step dies with the bank's contents; arrive[] is zeroed by the reset)
 
     def abort_step(self):
@@ -115,6 +192,7 @@ class KVBank:
     def state_init(self, width, mode, stride=1, layer_begin=0, layer_count=None):
         """mode 0 decoding (easykv/easykv.py:242-245); 1 prefill+keep_attention; 2 prefill (:412-416)."""
         lc = self.n_layers - layer_begin if layer_count is None else layer_count
+        self._ensure_ordered(layer_begin, lc)      # (the slot map is not rewritten by the initialisation)
         check(self.lib.ekv_state_init(C.byref(self._bank), layer_begin, lc, width, mode, stride, self._stream()), "ekv_state_init")
 
     def set_rope(self, cos, sin):
@@ -131,6 +209,7 @@ class KVBank:
     def load_rows(self, k, v, pos_begin=None, layer_begin=0):
         """Append ordered rows ``[layers, H, n, D]`` at positions [pos_begin, pos_begin+n)."""
         lc, n = k.shape[0], k.shape[2]
+        self._ensure_ordered(layer_begin, lc)
         pos = self.n_slots[layer_begin] if pos_begin is None else pos_begin
         k = k.to(self.device, torch.float16).contiguous()
         v = v.to(self.device, torch.float16).contiguous()
@@ -142,6 +221,7 @@ class KVBank:
     def ordered_kv(self, layer_begin=0, layer_count=None):
         """The ordered ``[layers, H, T, D]`` view the HF legacy tuple needs (birth order)."""
         lc = self.n_layers - layer_begin if layer_count is None else layer_count
+        self._ensure_ordered(layer_begin, lc)
         t = self.n_slots[layer_begin]
         k = torch.empty(lc, self.n_kv_heads, t, self.head_dim, dtype=torch.float16, device=self.device)
         v = torch.empty_like(k)
@@ -151,6 +231,7 @@ class KVBank:
     def compact_inplace(self, evict_ids, layer_begin=0):
         """Reference-shaped physical compaction for a bank kept in identity layout."""
         lc, _, kk = evict_ids.shape
+        self._ensure_ordered(layer_begin, lc)
         t = self.n_slots[layer_begin]
         ids = evict_ids.to(self.device, torch.int32).contiguous()
         check(self.lib.ekv_compact_inplace(C.byref(self._bank), layer_begin, lc, t, kk, _ptr(ids), self._stream()), "ekv_compact_inplace")
@@ -257,6 +338,8 @@ class KVBank:
         d = self._defer
         n = q.shape[2]
         t = self.n_slots[layer] + n
+        if self._slot_rows[layer]:
+            self._ensure_ordered(layer, 1)
         if d is None or d["plan"] is not plan or d["t"] != t or d["n"] != n:
             if d is not None and d["pending"]:
                 raise _lib.EkvError("attend(defer=True): the previous step was not flushed")
@@ -335,10 +418,23 @@ class KVBank:
             return self._attend_deferred(plan, q, k_new, v_new, layer_begin, out), None
         lc, _, n, _ = q.shape
         st = self.make_step(plan, n, layer_begin, lc)
-        st.phases = phases
+        # one-launch decode steps run on the slot-indexed layout of the score rows (nothing moves on an eviction); everything else
+        # on the ordered one
+        slot = n == 1 and phases == 0 and not overlap_scorer and self._enter_slot_rows(st)
+        if not slot:
+            self._ensure_ordered(layer_begin, lc)
+        st.phases = phases | (_lib.PHASE_SLOT_ROWS if slot else 0)
+        if slot and st.n_evict > 0:
+            tail = st.roco_tail if st.policy == _lib.POLICY_ROCO else st.win_tail
+            if all(tail <= self._slot_min_tail[l] for l in range(layer_begin, layer_begin + lc)):
+                st.phases |= _lib.PHASE_SLOT_TAIL_OK
+            for l in range(layer_begin, layer_begin + lc):
+                self._slot_min_tail[l] = min(self._slot_min_tail[l], tail)
         if out is None:
             out = torch.empty(lc, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
-        if st.n_evict > 0 and evict_ids is None:
+        if evict_ids is False:      # the caller has no use for the evicted order indices (the slot-indexed layout then skips ranking the victim)
+            evict_ids = None if slot else torch.empty(lc, self.n_kv_heads, max(st.n_evict, 1), dtype=torch.int32, device=self.device)
+        elif st.n_evict > 0 and evict_ids is None:
             evict_ids = torch.empty(lc, self.n_kv_heads, st.n_evict, dtype=torch.int32, device=self.device)
         if overlap_scorer and phases == 0 and not self.step_plan(plan, n, layer_begin, lc)[1]:
             self._attend_overlapped(st, q, k_new, v_new, out, evict_ids, lc, layer_begin)
@@ -351,7 +447,7 @@ class KVBank:
         need = self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st))
         ws = self._workspace(need)
         check(self.lib.ekv_step_attend(C.byref(self._bank), C.byref(st), _ptr(q), _ptr(k_new), _ptr(v_new), _ptr(out),
-                                       _ptr(evict_ids) if st.n_evict > 0 else None, _ptr(self.rope_cos), _ptr(self.rope_sin),
+                                       _ptr(evict_ids) if (st.n_evict > 0 and evict_ids is not None) else None, _ptr(self.rope_cos), _ptr(self.rope_sin),
                                        _ptr(ws), ws.numel(), self._stream()), "ekv_step_attend")
         if phases != 1:     # phases == 1 launches the attention kernel only; the slot map is untouched
             for l in range(layer_begin, layer_begin + lc):

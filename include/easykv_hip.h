@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define EKV_ABI_VERSION 5
+#define EKV_ABI_VERSION 6
 
 /* kv_policy strings of the reference -> codes (easykv/easykv.py:288-300, :310-362) */
 enum {
@@ -71,6 +71,9 @@ typedef struct ekv_bank {
   uint32_t *arrive; /* optional (ABI 3), uint32 [n_layers][n_kv_heads], zeroed by ekv_bank_reset and left zero by every call:
                        arrival counters of the split decode path.  With it the key-range partials of a head are folded inside the
                        attention kernel by the last split to arrive (no fold launch); NULL = separate fold kernel.            */
+  int32_t *birth;   /* optional (ABI 6), int32 [2][n_layers][n_kv_heads][cap] (order keys; the parked tail of the count rows) + */
+  float *slot_state;/* float [n_layers][n_kv_heads][2]: the slot-indexed layout of the score rows (EKV_PHASE_SLOT_ROWS); NULL = the
+                       bank only ever holds the ordered layout                                                                */
 } ekv_bank;
 
 /* One model forward over `layer_count` layers starting at `layer_begin` (all layers share the
@@ -169,6 +172,27 @@ int ekv_step_attend(const ekv_bank *bank, const ekv_step *step, const void *q, c
  * deferred scorer: per-layer phases = 1|4 calls append rows long before the phases = 8 call that scores them), so that a shape
  * the LAST call would refuse is refused before the FIRST one touches the bank. */
 int ekv_step_check(const ekv_bank *bank, const ekv_step *step);
+
+/* Slot-indexed score rows (ABI 6).  In the ordered layout an eviction shifts every entry of S / Q / C and of the slot map behind
+ * the victim: a decode step rewrites all of them (28 KB per head at 2 k slots), and written bytes cost about twice what read
+ * bytes do in the middle of the K/V stream.  ekv_rows_to_slots re-indexes the score rows of `layer_count` layers (n_slots live
+ * entries each) by PHYSICAL row — S[row], Q[row], a count base C0[row] in score_cnt (count = C0 + the head's running sum of
+ * count_add, slot_state[head][0]) and an order key birth[row] (the rank of `birth` among the live rows is the entry's order index;
+ * the next birth is slot_state[head][1] as int32) — after which a step with EKV_PHASE_SLOT_ROWS set in `phases` moves nothing on an
+ * eviction: the victim's row goes to the front of the free list (slot_of_pos[n_slots - 1]), S / Q of the live rows are rewritten,
+ * C0 / birth only for the appended row.  Decisions (victims, ties to the older entry) and reported ids (order indices) are those
+ * of the ordered layout.  While a layer is in this layout slot_of_pos[0, n_slots) is undefined and only steps with the flag may
+ * run on it; ekv_rows_to_order converts back (slot map, score rows and zero tails exactly as the ordered steps would have left
+ * them, counts included while all count_add were integers).  ekv_step_check / ekv_step_attend return EKV_E_UNSUPPORTED for a
+ * flagged step the layout does not cover: anything but a one-launch decode step (q_len = 1, phases otherwise 0) with plain keys, a
+ * scored policy with accumulate, score_off = 0, win_lo = 0, n_evict <= 1, GQA factor <= 4, phys_extent <= 2304, cap <= 9600. */
+#define EKV_PHASE_SLOT_ROWS 16
+/* with EKV_PHASE_SLOT_ROWS: the caller guarantees that this step's protected tail (roco: 10 entries; h2o_head: win_tail) is not
+ * longer than that of any earlier evicting step since ekv_rows_to_slots — the newest entries then have consecutive births and the
+ * kernel skips the counting check (one block reduction) that otherwise proves it, with an exact bisection when it fails */
+#define EKV_PHASE_SLOT_TAIL_OK 32
+int ekv_rows_to_slots(const ekv_bank *bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void *stream);
+int ekv_rows_to_order(const ekv_bank *bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void *stream);
 
 /* Ordered view: k_out/v_out fp16 [layer_count][n_kv_heads][n_slots][head_dim] <- rows in position order */
 int ekv_gather_ordered(const ekv_bank *bank, int32_t layer_begin, int32_t layer_count, int32_t n_slots, void *k_out,

@@ -40,7 +40,8 @@ def test_abi_exports_every_declared_symbol():
     raw = ctypes.CDLL(_build.LIB)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.ekv_abi_version() == 5
+    assert lib.ekv_abi_version() == 6
+    assert lib.ekv_rows_to_slots(None, 0, 1, 1, None) == -1 and lib.ekv_rows_to_order(None, 0, 1, 1, None) == -1
     assert lib.ekv_step_info(None, None, None, 0) == -1
     assert b"workspace" in lib.ekv_strerror(-3)
     # argument checking happens before any device access: callable without a GPU
@@ -50,7 +51,7 @@ def test_abi_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from easykv_amd._lib import Bank, Step
-    assert ctypes.sizeof(Bank) == 6 * 8 + 5 * 4 + 4 + 8      # 6 pointers, 5 int32, padding, the optional arrive pointer
+    assert ctypes.sizeof(Bank) == 6 * 8 + 5 * 4 + 4 + 3 * 8      # 6 pointers, 5 int32, padding, the optional arrive / birth / slot_state pointers
     assert ctypes.sizeof(Step) == 18 * 4 + 5 * 4 + 2 * 4
     header = open(os.path.join(ROOT, "include", "easykv_hip.h")).read()
     body = header[header.index("typedef struct ekv_step {"):header.index("} ekv_step;")]
@@ -174,7 +175,7 @@ def test_sampler_matches_reference_fixture():
 
 def _fake_bank_step(head_dim=128, hq=32, h=32, cap=2112, n_layers=2, **step):
     from easykv_amd._lib import Bank, Step
-    bank = Bank(256, 256, 256, 256, 256, 256, n_layers, hq, h, head_dim, cap, None)     # (never dereferenced by a dry run)
+    bank = Bank(256, 256, 256, 256, 256, 256, n_layers, hq, h, head_dim, cap, None, 256, 256)     # (never dereferenced by a dry run)
     st = Step()
     st.layer_begin, st.layer_count, st.q_len, st.n_slots, st.score_off = 0, n_layers, 1, 2049, 0
     st.policy, st.accumulate, st.n_evict, st.roco_k1, st.roco_tail, st.range_start = 2, 1, 1, 1434, 10, -1
@@ -202,3 +203,16 @@ def test_step_check_is_a_dry_run_of_step_attend():
     # score rows wider than any scorer's LDS (W > ~39 000 columns) are refused before anything is launched
     assert ok(*_fake_bank_step(cap=60032, n_slots=60000, roco_k1=30000, n_split=-1)) == -2
     assert lib.ekv_step_check(None, None) == -1
+    # slot-indexed score rows (ABI 6, EKV_PHASE_SLOT_ROWS = 16): only the one-launch decode step of a shape the layout covers
+    slot = dict(n_layers=32, layer_count=32, phases=16, phys_extent=2112)
+    assert ok(*_fake_bank_step(**slot)) == 0
+    assert ok(*_fake_bank_step(**dict(slot, phases=16 | 32))) == 0             # + "the protected tail is known to be consecutive"
+    assert ok(*_fake_bank_step(**dict(slot, score_off=5))) == -2               # a scored window that is not the whole cache
+    assert ok(*_fake_bank_step(**dict(slot, policy=1, win_lo=4, win_tail=100))) == -2   # a sink window needs ranks
+    assert ok(*_fake_bank_step(**dict(slot, rope_on_read=1))) == -2
+    assert ok(*_fake_bank_step(**dict(slot, count_add=1.5))) == -2             # counts must stay integers
+    assert ok(*_fake_bank_step(**dict(slot, n_layers=2, layer_count=1))) == -2 # a one-layer launch is split: not the one-launch step
+    assert ok(*_fake_bank_step(**dict(slot, q_len=8, n_slots=2064, n_evict=8, roco_k1=1847, win_lo=4, win_tail=205))) == -2   # chunk steps read the ordered layout
+    b, s = _fake_bank_step(**slot)
+    b.birth = None
+    assert ok(b, s) == -2                                                      # a bank without the slot-layout arrays
