@@ -797,6 +797,7 @@ def decode_run(args, dev, rank, world, scaling, DS, want_seq):
     pending.clear()
     DS.barrier(dev)
     elapsed = DS.max_over_ranks(time.perf_counter() - t0, dev)
+    slot_rows = bool(any(getattr(bank, "_slot_rows", [False])))      # layout of the score rows the timed steps ran on
     if graph is not None:   # per-kernel durations: a short eager pass with HIP events
         for i in range(args.steps):
             step(0, i)
@@ -825,7 +826,7 @@ def decode_run(args, dev, rank, world, scaling, DS, want_seq):
             seq = n_seq / (time.perf_counter() - ts)
     t_region = region[0].elapsed_time(region[1]) / args.steps * 1e-3
     return dict(elapsed=elapsed, t_region=t_region, ev=ev, per_step_events=per_step_events, n_split=n_split, fused=fused, lpl=lpl,
-                L=L, shard=shard, n_pre=n_pre, seq=seq, handoff=handoff_on, sync_handoff=sync_handoff, T=T, H=H)
+                L=L, shard=shard, n_pre=n_pre, seq=seq, handoff=handoff_on, sync_handoff=sync_handoff, T=T, H=H, slot_rows=slot_rows)
 
 
 def latest_pmc_summary(L, Hq, H, D, budget, policy, lpl):
@@ -911,6 +912,7 @@ def main():
     ap.add_argument("--step-events", action="store_true", help="fused path: bracket every launch with its own HIP event pair instead "
                     "of one pair around the timed region (adds ~6 us of marker latency per step)")
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from profiles/ instead of two rocprofv3 --pmc child runs")
+    ap.add_argument("--ordered-rows", action="store_true", help="keep the score rows in the ordered layout (A/B switch for the slot-indexed layout of ABI 6)")
     ap.add_argument("--no-prefill", action="store_true", help="skip the secondary strided-prefill (configs[1]) figures")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-kernel bandwidth figures")
     ap.add_argument("--no-handoff", action="store_true")
@@ -926,6 +928,9 @@ def main():
     args = ap.parse_args()
 
     from easykv_amd import dist as DS
+    if args.ordered_rows:
+        from easykv_amd.engine import KVBank as _KVBank
+        _KVBank.use_slot_rows = False
     if args.same_device:
         os.environ["LOCAL_RANK"] = "0"
     rank, local_rank, world = DS.init(args.backend)
@@ -964,6 +969,8 @@ def main():
                                if args.scaling == "strong" else f"{world} x {L}-layer blocks, layer-parallel") if world > 1 else "1 GPU",
                "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [r["shard"].begin, r["shard"].end], "n_split": r["n_split"],
                "fused": fused, "slot_map": "identity" if args.identity_layout else "scattered (random permutation: long-run steady state)",
+               "score_rows": "slot-indexed (ABI 6: S / Q rewritten per step, count base + birth once per row, no compaction)" if r["slot_rows"] else "ordered",
+
                "prewarm_steps": r["n_pre"], "hipgraph": bool(args.graph), "overlap_scorer": bool(args.overlap_scorer),
                "handoff": ("sync: launch ordered behind the previous stage's activation" if r["sync_handoff"] else "overlapped with the next launch") if r["handoff"] else False}
         line = {
