@@ -465,7 +465,7 @@ static bool ekv_slot_rows_supported_impl(const ekv_bank* bank, const ekv_step* s
   if (!bank->birth || !bank->slot_state || !scored || st->q_len != 1 || st->rope_on_read || st->n_evict > 1) return false;
   if (st->score_off != 0 || st->win_lo != 0 || st->tova_head_mean || rep > 4 || !st->accumulate) return false;
   if (st->count_add != (float)(int)st->count_add) return false;      // counts stay exact integers (count = base + running sum)
-  const int max_rows = fused_nw == 8 ? 512 * 5 : 256 * 9;
+  const int max_rows = 6144;      // (columns per thread in registers: 5 / 9 up to 2560 / 2304 rows, 12 / 24 beyond — 8-wave / 4-wave build)
   if (phys_extent > max_rows || bank->cap > 9600) return false;      // (cap: ekv_rows_to_order stages four rows of `cap` words in LDS)
   return 2 * ekv_align((size_t)phys_extent, 256) <= 3 * ekv_align((size_t)t_pad, 256);      // (LDS: two rows over [0, E) instead of three over [0, T))
 }

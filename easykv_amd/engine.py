@@ -126,6 +126,8 @@ class KVBank:
         key = bytes(st)
         ok = self._slot_ok.get(key)
         if ok is None:
+            if len(self._slot_ok) > 4096:      # (a growing cache asks about a new shape every step)
+                self._slot_ok.clear()
             ok = self._slot_ok[key] = self.lib.ekv_step_check(C.byref(self._bank), C.byref(st)) == 0
         st.phases = 0
         if not ok:
@@ -411,7 +413,9 @@ class KVBank:
     def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None, phases=0, overlap_scorer=False, defer=False):
         """q ``[layers, Hq, n, D]``, k_new/v_new ``[layers, H, n, D]`` (fp16, device).
         Returns (out ``[layers, Hq, n, D]`` fp16, evict_ids ``[layers, H, k]`` int32 or None).
-        ``defer=True`` (one layer per call): attention + fold only; the scorers of all layers run at :meth:`flush`."""
+        ``defer=True`` (one layer per call): attention + fold only; the scorers of all layers run at :meth:`flush`.
+        ``evict_ids=False``: the caller has no use for the evicted cache indices (none are returned; on the slot-indexed layout the
+        step then skips ranking the victim's birth)."""
         if defer:
             if q.shape[0] != 1 or phases != 0:
                 raise ValueError("defer=True is for one-layer calls")

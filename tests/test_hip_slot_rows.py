@@ -112,6 +112,12 @@ def test_long_run_on_the_slot_layout_equals_the_ordered_layout(policy, D, rep):
     _run([(policy, 1200)], L=2, Hq=4 * rep, H=4, D=D, budget=120, seed=300 + D + rep)
 
 
+def test_extents_beyond_2304_rows():
+    """The builds with 24 (4-wave) thread-owned columns: a budget of 3000."""
+    _run([("roco", 60)], L=2, Hq=4, H=4, D=128, budget=3000, seed=21)
+    _run([("h2o_head", 30)], L=1, Hq=8, H=4, D=128, budget=2500, seed=22)
+
+
 def test_a_growing_protected_tail_takes_the_exact_bisection():
     """roco protects the 10 newest entries, h2o_head the newest 30 % of the budget: after a stretch of roco steps the newest 36
     entries are NOT consecutive births any more (roco evicted some of them), so the h2o_head steps cannot take ``nb - tail`` as the
@@ -120,11 +126,12 @@ def test_a_growing_protected_tail_takes_the_exact_bisection():
     _run([("roco", 150), ("h2o_head", 60)], L=2, Hq=4, H=4, D=128, budget=120, seed=11)
 
 
-def test_llama_shape_launch_and_growth_steps():
+@pytest.mark.parametrize("budget_8w", [700, 2700])      # (2700: the 12-column build of the 8-wave kernel)
+def test_llama_shape_launch_and_growth_steps(budget_8w):
     """The 8-wave kernel build (256..512 heads per launch; the tests above run the 4-wave one) at a budget of 700, starting BELOW the
     budget: the first steps append without evicting (rows come from the never-used part of the free list), then the steady state."""
     from easykv_amd import KVBank, StepPlan
-    L, Hq, H, D, budget, fill = 16, 32, 32, 128, 700, 690
+    L, Hq, H, D, budget, fill = 16, 32, 32, 128, budget_8w, budget_8w - 10
     g = torch.Generator().manual_seed(5)
     k0, v0 = _mk(L, H, fill, D, g=g), _mk(L, H, fill, D, g=g)
     banks = []
