@@ -176,8 +176,10 @@ __global__ void __launch_bounds__(256) ekv_rows_to_slots_kernel(const int32_t* s
     birth[head_row + row] = j;
   }
   if (tid == 0) {
-    slot_state[2 * head] = 0.f;
-    reinterpret_cast<int32_t*>(slot_state)[2 * head + 1] = T;
+    slot_state[4 * head] = 0.f;
+    reinterpret_cast<int32_t*>(slot_state)[4 * head + 1] = T;
+    reinterpret_cast<uint32_t*>(slot_state)[4 * head + 2] = 0u;      // no threshold hint yet
+    reinterpret_cast<uint32_t*>(slot_state)[4 * head + 3] = 0u;
   }
 }
 
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(256) ekv_rows_to_order_kernel(int32_t* slot_of
   const int h = blockIdx.x, ll = blockIdx.y, tid = threadIdx.x;
   const size_t head = (size_t)(layer_begin + ll) * n_kv_heads + h, head_row = head * cap;
   int32_t* s_b = reinterpret_cast<int32_t*>(s_rows) + 3 * (size_t)cap;
-  const float g = slot_state[2 * head];
+  const float g = slot_state[4 * head];
   for (int r = tid; r < cap; r += 256) {
     s_rows[r] = S[head_row + r];
     s_rows[cap + r] = Q ? Q[head_row + r] : 0.f;

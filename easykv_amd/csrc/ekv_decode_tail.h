@@ -505,6 +505,10 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
     livem |= (lv ? 1u : 0u) << it;
   }
   auto lives = [&](int it) { return (livem >> it) & 1u; };
+  // select scratch: histogram bins [0, 256), [256] listed so far, [257] bin, [258] below, [260..261] threshold, [262] victim row —
+  // zeroed here, published by the softmax reduction's barrier (slot-layout steps always accumulate)
+  if (tid < 256) s_hist[tid] = 0;
+  if (tid < 8) s_hist[256 + tid] = 0;
   // ---- exact softmax over the live rows, GQA fold, accumulate (easykv/easykv.py:271-300); S / Q go back to HBM right away ----
   if (sc.accumulate) {
     float mx[REP], sm[REP];
@@ -553,8 +557,8 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
   if (tid == 0) {      // the appended row's count base (c_new: what the ordered row holds behind its live entries, minus g) and birth
     sc.score_cnt[head_row + new_row] = c_new;
     sc.birth[head_row + new_row] = nb;
-    sc.slot_state[2 * head] = g_new;
-    reinterpret_cast<int32_t*>(sc.slot_state)[2 * head + 1] = nb + 1;
+    sc.slot_state[4 * head] = g_new;
+    reinterpret_cast<int32_t*>(sc.slot_state)[4 * head + 1] = nb + 1;
   }
   if (sc.n_evict != 1) return;
 
@@ -612,12 +616,48 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
       }
       kstd[it] = key;
     }
-    if (tid < 256) s_hist[tid] = 0;
-    if (tid < 8) s_hist[256 + tid] = 0;
-    red.min2_u32(kmin, nmax);
-    const uint32_t kmax = ~nmax;
     unsigned long long thr = 0;
-    if (kmin <= kmax) {
+    // Warm start: the threshold key of the previous step (slot_state[head][2]).  A step adds one probability to every column, so the
+    // k1-th smallest std moves by a fraction of a percent: count the keys below a narrow window around the hint and list the window's
+    // members in the SAME pass — one reduction and one ranking barrier instead of range + histogram + scan + list + ranking.  Exact:
+    // when the window misses (first step, a jump) the full select below runs.
+    const uint32_t hint = reinterpret_cast<const uint32_t*>(sc.slot_state)[4 * head + 2];
+    if (hint != 0u) {
+      constexpr uint32_t kWin = 1u << 15;      // +- 2^15 ulps = +- 0.4 % of the key: a handful of the ~2000 columns
+      const uint32_t lo = hint > kWin ? hint - kWin : 0u, hi = hint < kSent - kWin ? hint + kWin : kSent - 1u;
+      int below = 0;                           // (the list counter was zeroed at the top of the tail, behind the softmax reduction's barrier)
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        if (lives(it)) {
+          below += kstd[it] < lo ? 1 : 0;
+          if (kstd[it] >= lo && kstd[it] <= hi) {
+            const uint32_t at = atomicAdd(&s_hist[256], 1u);
+            if ((int)at < list_cap) s_list[at] = comp(it);
+          }
+        }
+      }
+      below = red.sum_int(below);
+      const int in_win = (int)s_hist[256];
+      if (below < sc.roco_k1 && sc.roco_k1 <= below + in_win && in_win <= list_cap && in_win <= NT) {
+        if (tid < in_win) {
+          const unsigned long long e = s_list[tid];
+          uint32_t rank = 0;
+          for (int i = 0; i < in_win; ++i) rank += s_list[i] < e ? 1u : 0u;
+          if (below + (int)rank == sc.roco_k1 - 1) *reinterpret_cast<unsigned long long*>(s_hist + 260) = e + 1ull;
+        }
+        __syncthreads();
+        thr = *reinterpret_cast<const unsigned long long*>(s_hist + 260);
+      } else {
+        __syncthreads();                       // (everybody has read the counter)
+        if (tid == 0) s_hist[256] = 0;
+      }
+    }
+    uint32_t kmax = 0;
+    if (thr == 0) {
+      red.min2_u32(kmin, nmax);
+      kmax = ~nmax;
+    }
+    if (thr == 0 && kmin <= kmax) {
       const uint32_t range = kmax - kmin;
       const int shift = range < 256u ? 0 : 24 - __clz(range);
       auto bin_of = [&](uint32_t k) { return k >= kSent ? 255u : min(255u, (k - kmin) >> shift); };
@@ -690,6 +730,10 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
         bound = lo;
       }
       thr = ((unsigned long long)tau << 32) | (uint32_t)bound;
+    }
+    if (tid == 0) {      // hint for the next step: the key of the k1-th smallest composite (0 = none: sentinel keys make no useful pivot)
+      const uint32_t kt = (uint32_t)((thr - 1ull) >> 32);
+      reinterpret_cast<uint32_t*>(sc.slot_state)[4 * head + 2] = (thr != 0 && kt < kSent && kt != 0u) ? kt : 0u;
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {

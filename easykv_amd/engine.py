@@ -67,7 +67,7 @@ class KVBank:
         # slot-indexed score rows (include/easykv_hip.h, EKV_PHASE_SLOT_ROWS): order keys, (count offset, next birth) per head, and
         # which layers currently hold that layout
         self.birth = torch.zeros(2, n_layers, n_kv_heads, cap, dtype=torch.int32, device=dev) if scored else None
-        self.slot_state = torch.zeros(n_layers, n_kv_heads, 2, dtype=torch.float32, device=dev) if scored else None
+        self.slot_state = torch.zeros(n_layers, n_kv_heads, 4, dtype=torch.float32, device=dev) if scored else None
         self._slot_rows = [False] * n_layers
         self._slot_min_tail = [1 << 30] * n_layers      # smallest protected tail of an evicting step since the conversion
         self._slot_ok = {}        # step shape -> does the slot-indexed decode kernel take it (ekv_step_check)
