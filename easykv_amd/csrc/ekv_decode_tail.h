@@ -467,21 +467,6 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
 // ordered layout states as index ranges — the newest `tail` entries — are birth thresholds, exact by a counting check with a
 // bisection fallback.  ekv_rows_to_slots / ekv_rows_to_order convert between the layouts (ekv_abi.hip).
 // Thread t owns rows t, t + NT, ...: every pass touches its own columns only, so the passes need no barrier between them.
-// x / d for several x of one d: the refinement chain of the IEEE division hipcc emits (v_rcp_f32, one Newton step on the
-// reciprocal, quotient = x * r and two residual corrections) without its v_div_scale / v_div_fmas / v_div_fixup wrapper — those
-// handle denormal, infinite and zero operands; the counts here are >= 1 and the sums normal.  Bit-identical to `/` on 2 x 6.9e10
-// random operand pairs on MI355X (numerators 2^-66 .. 2^20, divisors integers 1 .. 2^20 and arbitrary floats 2^-10 .. 2^30), and
-// the reciprocal is shared: two quotients cost 13 instructions instead of 24.
-__device__ __forceinline__ float ekv_rcp_refined(float d) {
-  const float r = __builtin_amdgcn_rcpf(d);
-  return fmaf(fmaf(-d, r, 1.f), r, r);
-}
-__device__ __forceinline__ float ekv_div_by(float x, float d, float r) {
-  float q = x * r;
-  q = fmaf(fmaf(-d, q, x), r, q);
-  return fmaf(fmaf(-d, q, x), r, q);
-}
-
 // S / Q are staged in LDS by LDS-DMA under the stream (like the ordered layout's rows); C0 and birth come straight into registers
 // (`cB`, `cC`: loads issued by the caller when its stream ends, consumed after the softmax passes) — a third and fourth LDS row
 // would cost the fourth workgroup per CU.
@@ -603,9 +588,8 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
       uint32_t key = ~0u;
       if (lives(it)) {
         const float c = rC[it] + g_new;
-        const float rc = ekv_rcp_refined(c);
-        const float mean = ekv_div_by(sS[j], c, rc);
-        float sd = sqrtf(ekv_div_by(sQ[j], c, rc) - mean * mean);
+        const float mean = sS[j] / c;          // (IEEE divisions: a shared refined reciprocal without the v_div_scale / v_div_fixup wrapper
+        float sd = sqrtf(sQ[j] / c - mean * mean);   //  is bit-identical only while numerator * 2^-24 stays normal — sums of p^2 do not)
         if (rB[it] > b_prot) sd = 1e9f;
         key = ekv_fkey(sd);
         kmean[j] = ekv_fkey(mean);               // for the arg-min over the feasible set below (own column of the dead e row)
