@@ -194,7 +194,8 @@ class BudgetedKVCache:
                 if self._cur is not None and ids is not None:
                     self._cur.extend(ids[l] for l in range(self.layer_count))
             return out
-        out, ids = self.bank.attend(plan, q, k, v, layer_begin=layer_idx)
+        # (the evicted cache indices are only wanted when a caller records them: _record_evictions)
+        out, ids = self.bank.attend(plan, q, k, v, layer_begin=layer_idx, evict_ids=None if self._cur is not None else False)
         if self._cur is not None and ids is not None:
             self._cur.append(ids[0])
         return out

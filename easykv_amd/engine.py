@@ -436,6 +436,7 @@ class KVBank:
                 self._slot_min_tail[l] = min(self._slot_min_tail[l], tail)
         if out is None:
             out = torch.empty(lc, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
+        want_ids = evict_ids is not False
         if evict_ids is False:      # the caller has no use for the evicted order indices (the slot-indexed layout then skips ranking the victim)
             evict_ids = None if slot else torch.empty(lc, self.n_kv_heads, max(st.n_evict, 1), dtype=torch.int32, device=self.device)
         elif st.n_evict > 0 and evict_ids is None:
@@ -445,7 +446,7 @@ class KVBank:
             for l in range(layer_begin, layer_begin + lc):
                 self.n_slots[l] = st.n_slots - st.n_evict
                 self.extent[l] = st.phys_extent
-            return out, (evict_ids if st.n_evict > 0 else None)
+            return out, (evict_ids if (st.n_evict > 0 and want_ids) else None)
         if any(ev is not None for ev in self._score_done[layer_begin:layer_begin + lc]):
             self.join()
         need = self.lib.ekv_workspace_bytes(C.byref(self._bank), C.byref(st))
@@ -458,4 +459,4 @@ class KVBank:
                 self.n_slots[l] = st.n_slots - st.n_evict
         for l in range(layer_begin, layer_begin + lc):      # the new rows are written by the attention kernel
             self.extent[l] = st.phys_extent
-        return out, (evict_ids if st.n_evict > 0 else None)
+        return out, (evict_ids if (st.n_evict > 0 and want_ids) else None)
