@@ -71,6 +71,7 @@ class KVBank:
         self._slot_rows = [False] * n_layers
         self._slot_min_tail = [1 << 30] * n_layers      # smallest protected tail of an evicting step since the conversion
         self._slot_ok = {}        # step shape -> does the slot-indexed decode kernel take it (ekv_step_check)
+        self._slot_stretch = self._slot_short = 0      # steps since the layout was entered; short stretches seen (see _ensure_ordered)
         self.n_slots = [0] * n_layers
         # High-water mark of live rows per layer.  The library keeps the free list as [freed rows (most recent first), never-
         # used rows ascending] and appends take from its front, so every live row has a physical index < extent: the
@@ -112,6 +113,10 @@ class KVBank:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.EkvError("a layout change of the score rows cannot be captured in a graph: run the step once outside the capture")
             check(self.lib.ekv_rows_to_order(C.byref(self._bank), l, m - l, self.n_slots[l], self._stream()), "ekv_rows_to_order")
+            # a caller that alternates between one-launch decode steps and anything that reads the ordered layout pays two
+            # conversions per step (~0.2 ms per 256 heads each): after a few stretches of under 16 steps the bank stays ordered
+            self._slot_short = self._slot_short + 1 if self._slot_stretch < 16 else max(0, self._slot_short - 1)
+            self._slot_stretch = 0
             for i in range(l, m):
                 self._slot_rows[i] = False
             l = m
@@ -120,7 +125,7 @@ class KVBank:
         """Decide whether this one-launch decode step runs on the slot-indexed layout, converting its layers if it does."""
         lb, lc = st.layer_begin, st.layer_count
         rows = self._slot_rows[lb:lb + lc]
-        if not (self.use_slot_rows and self._score_sum is not None) or len(set(self.n_slots[lb:lb + lc])) != 1:
+        if not (self.use_slot_rows and self._score_sum is not None) or len(set(self.n_slots[lb:lb + lc])) != 1 or self._slot_short >= 4:
             return False
         st.phases = _lib.PHASE_SLOT_ROWS
         key = bytes(st)
@@ -140,6 +145,7 @@ class KVBank:
             for i in range(lb, lb + lc):
                 self._slot_rows[i] = True
                 self._slot_min_tail[i] = 1 << 30      # (births = order indices: every tail is consecutive)
+        self._slot_stretch += 1
         return True
 
     @property
@@ -177,6 +183,7 @@ class KVBank:
         self.extent = [0] * self.n_layers
         self._slot_rows = [False] * self.n_layers
         self._slot_min_tail = [1 << 30] * self.n_layers
+        self._slot_stretch = self._slot_short = 0
         self._defer = None      # (a half-open deferred token step dies with the bank's contents; arrive[] is zeroed by the reset)
 
     def abort_step(self):
@@ -425,8 +432,8 @@ class KVBank:
         # one-launch decode steps run on the slot-indexed layout of the score rows (nothing moves on an eviction); everything else
         # on the ordered one
         slot = n == 1 and phases == 0 and not overlap_scorer and self._enter_slot_rows(st)
-        if not slot:
-            self._ensure_ordered(layer_begin, lc)
+        if not slot and any(self._slot_rows[layer_begin:layer_begin + lc]):
+            self._ensure_ordered()      # (all layers in one launch: a layer-per-call caller would otherwise convert 32 times)
         st.phases = phases | (_lib.PHASE_SLOT_ROWS if slot else 0)
         if slot and st.n_evict > 0:
             tail = st.roco_tail if st.policy == _lib.POLICY_ROCO else st.win_tail

@@ -191,3 +191,21 @@ def test_other_steps_convert_back_first():
     assert not any(b._slot_rows)
     assert torch.equal(outs[0][1], outs[1][1]) and torch.allclose(outs[0][0].float(), outs[1][0].float(), atol=1e-3, rtol=0)
     assert torch.equal(a.slot_of_pos[:, :, :120], b.slot_of_pos[:, :, :120]) and torch.equal(a.score_cnt, b.score_cnt)
+
+
+def test_a_caller_that_flips_the_layout_every_step_ends_up_on_the_ordered_one():
+    """Reading the ordered state after every decode step costs two conversions per step: after four short stretches the bank stops
+    entering the slot-indexed layout (results unchanged either way)."""
+    from easykv_amd import StepPlan
+    (a, b), g = _banks(2, 4, 4, 128, 120, seed=8)
+    plan = StepPlan(policy="roco", phase="decode", evict=True, score_off=0, budget=120, n_split=1)
+    used = []
+    for i in range(10):
+        q, k, v = _mk(2, 4, 1, 128, g=g).cuda(), _mk(2, 4, 1, 128, g=g).cuda(), _mk(2, 4, 1, 128, g=g).cuda()
+        ia, ib = a.attend(plan, q, k, v)[1], b.attend(plan, q, k, v)[1]
+        used.append(all(b._slot_rows))
+        assert torch.equal(ia, ib)
+        assert torch.equal(a.score_cnt, b.score_cnt)          # (reads the ordered state: converts b back)
+    assert used[:4] == [True] * 4 and used[-1] is False
+    b.reset()
+    assert b._slot_short == 0
