@@ -606,6 +606,7 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
 
   sa.big_rows = ws.big_rows;
   sa.big_stride = ws.t_pad;
+  sa.slot_state = bank->slot_state;      // (word [3] of a head: threshold hint of the logits-in-LDS chunk kernel, whatever the layout)
 
   drop_stale_error();
   // whole decode step in one launch when no head has to be split

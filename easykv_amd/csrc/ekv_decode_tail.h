@@ -607,7 +607,10 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
     // when the window misses (first step, a jump) the full select below runs.
     const uint32_t hint = reinterpret_cast<const uint32_t*>(sc.slot_state)[4 * head + 2];
     if (hint != 0u) {
-      constexpr uint32_t kWin = 1u << 15;      // +- 2^15 ulps = +- 0.4 % of the key: a handful of the ~2000 columns
+#ifndef EKV_SLOT_WARM_WIN
+#define EKV_SLOT_WARM_WIN 15
+#endif
+      constexpr uint32_t kWin = 1u << EKV_SLOT_WARM_WIN;      // +- 2^15 ulps = +- 0.4 % of the key: a handful of the ~2000 columns
       const uint32_t lo = hint > kWin ? hint - kWin : 0u, hi = hint < kSent - kWin ? hint + kWin : kSent - 1u;
       int below = 0;                           // (the list counter was zeroed at the top of the tail, behind the softmax reduction's barrier)
 #pragma unroll

@@ -82,7 +82,7 @@ struct EkvScoreArgs {
   float count_add, count_tail_step;
   int32_t skip_fold;   // 1: the attention output was already folded by ekv_fold_kernel (scorer off the critical path)
   // slot-indexed score rows (ekv_step.phases & EKV_PHASE_SLOT_ROWS, fused decode step; ekv_decode_tail.h): score_sum / score_sq /
-  // score_cnt are indexed by physical row, score_cnt holds the count base, birth[row] the order key, slot_state[head] = (g, next birth, last roco threshold key, spare)
+  // score_cnt are indexed by physical row, score_cnt holds the count base, birth[row] the order key, slot_state[head] = (g, next birth, threshold hint of the decode step, threshold hint of the chunk_lds kernel — the hints in any layout)
   int32_t* birth;
   float* slot_state;
   float* cnt_tail;        // parked tail of the ordered count row (second half of ekv_bank.birth)

@@ -178,7 +178,8 @@ int ekv_step_check(const ekv_bank *bank, const ekv_step *step);
  * bytes do in the middle of the K/V stream.  ekv_rows_to_slots re-indexes the score rows of `layer_count` layers (n_slots live
  * entries each) by PHYSICAL row — S[row], Q[row], a count base C0[row] in score_cnt (count = C0 + the head's running sum of
  * count_add, slot_state[head][0]) and an order key birth[row] (the rank of `birth` among the live rows is the entry's order index;
- * the next birth is slot_state[head][1] as int32; [2] = the last step's roco threshold key, a hint for the next select, [3] spare) — after which a step with EKV_PHASE_SLOT_ROWS set in `phases` moves nothing on an
+ * the next birth is slot_state[head][1] as int32; [2] = the last decode step's roco threshold key, a hint for the next select; [3] = the same for the logits-in-LDS chunk kernel,
+ * which uses it on the ordered layout too) — after which a step with EKV_PHASE_SLOT_ROWS set in `phases` moves nothing on an
  * eviction: the victim's row goes to the front of the free list (slot_of_pos[n_slots - 1]), S / Q of the live rows are rewritten,
  * C0 / birth only for the appended row.  Decisions (victims, ties to the older entry) and reported ids (order indices) are those
  * of the ordered layout.  While a layer is in this layout slot_of_pos[0, n_slots) is undefined and only steps with the flag may
