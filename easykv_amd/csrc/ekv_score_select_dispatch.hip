@@ -1,5 +1,6 @@
 // Block-size dispatch of the generic scorer: 256-thread workgroups when the grid alone fills the chip (more workgroups
 // resident per CU, cheaper barriers), 512 threads when there are few (head, layer) pairs.
+#include <cstdlib>
 #include "ekv_common.h"
 #include "ekv_kernels.h"
 
@@ -22,6 +23,10 @@ hipError_t ekv_launch_score_select(const EkvScoreArgs& a, int layer_count, hipSt
   // 256 threads only while at least three such workgroups fit a CU's LDS; wide score rows (C4: W = 5098 -> 82 KB) leave
   // room for one workgroup per CU, which must then bring 512 threads
   if (a.big_rows != nullptr) return ekv_launch_score_select_nt1024(a, layer_count, s);   // rows in global scratch, keys in LDS
+  static const int force = [] { const char* e = std::getenv("EKV_SS_NT"); return e ? std::atoi(e) : 0; }();   // (A/B knob: 256 / 512 / 1024)
+  if (force == 256 && ekv_score_lds_bytes_nt256(a) <= 160 * 1024) return ekv_launch_score_select_nt256(a, layer_count, s);
+  if (force == 512 && ekv_score_lds_bytes_nt512(a) <= 160 * 1024) return ekv_launch_score_select_nt512(a, layer_count, s);
+  if (force == 1024 && ekv_score_lds_bytes_nt1024(a) <= 160 * 1024) return ekv_launch_score_select_nt1024(a, layer_count, s);
   const bool small_blocks = a.n_kv_heads * layer_count >= 768 && ekv_score_lds_bytes_nt256(a) <= 53 * 1024;
   if (small_blocks) return ekv_launch_score_select_nt256(a, layer_count, s);
   // one workgroup per CU either way (at most one (head, layer) pair per CU, or LDS rows too wide for two): give it all 16
