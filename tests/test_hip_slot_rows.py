@@ -22,10 +22,18 @@ def _mk(*shape, g):
     return torch.randn(*shape, generator=g).half()
 
 
-def _banks(L, Hq, H, D, budget, seed, scatter=True):
+def _heavy(k, g):
+    """Keys with log-normal norms: a broad score distribution (a few columns take most of the attention), unlike i.i.d. normal keys —
+    the selects' warm-start windows miss far more often on it and their exact fall-backs run."""
+    return (k.float() * torch.exp(1.2 * torch.randn(*k.shape[:-1], 1, generator=g))).half()
+
+
+def _banks(L, Hq, H, D, budget, seed, scatter=True, heavy=False):
     from easykv_amd import KVBank
     g = torch.Generator().manual_seed(seed)
     k0, v0 = _mk(L, H, budget, D, g=g), _mk(L, H, budget, D, g=g)
+    if heavy:
+        k0 = _heavy(k0, g)
     perm = torch.argsort(torch.rand(L, H, budget, generator=g), dim=-1).int()
     banks = []
     for slot in (False, True):
@@ -61,9 +69,9 @@ def _near_tie(policy, S0, Q0, C0, keys, q, budget, va, vb, roco_tail=10):
     return on_edge or abs(float(mean[va] - mean[vb])) <= 1e-6 * abs(float(mean[va]))
 
 
-def _run(policy_schedule, L, Hq, H, D, budget, seed, min_alive=0.75):
+def _run(policy_schedule, L, Hq, H, D, budget, seed, min_alive=0.75, heavy=False):
     from easykv_amd import StepPlan
-    (a, b), g = _banks(L, Hq, H, D, budget, seed)
+    (a, b), g = _banks(L, Hq, H, D, budget, seed, heavy=heavy)
     alive = torch.ones(L, H, dtype=torch.bool)
     T = budget + 1
     rep = Hq // H
@@ -72,7 +80,7 @@ def _run(policy_schedule, L, Hq, H, D, budget, seed, min_alive=0.75):
         plan = StepPlan(policy=policy, phase="decode", evict=True, score_off=0, budget=budget, n_split=1)
         assert a.step_plan(plan, 1) == (1, True)                   # the one-launch decode step
         for i in range(steps):
-            q, k, v = _mk(L, Hq, 1, D, g=g).cuda(), _mk(L, H, 1, D, g=g).cuda(), _mk(L, H, 1, D, g=g).cuda()
+            q, k, v = _mk(L, Hq, 1, D, g=g).cuda(), (_heavy(_mk(L, H, 1, D, g=g), g) if heavy else _mk(L, H, 1, D, g=g)).cuda(), _mk(L, H, 1, D, g=g).cuda()
             S0, Q0, C0 = a.score_sum.clone(), a.score_sq.clone(), a.score_cnt.clone()
             K0, _ = a.ordered_kv()
             oa, ia = a.attend(plan, q, k, v)
@@ -110,6 +118,13 @@ def test_long_run_on_the_slot_layout_equals_the_ordered_layout(policy, D, rep):
     """1200 evicting decode steps without ever leaving the slot-indexed layout (births run far past the cache length, every row is
     recycled many times), then the conversion back."""
     _run([(policy, 1200)], L=2, Hq=4 * rep, H=4, D=D, budget=120, seed=300 + D + rep)
+
+
+def test_long_run_on_a_broad_score_distribution():
+    """Keys with log-normal norms (a few columns take most of the probability mass): thresholds jump, the warm-started select misses
+    and the full select / the bisection run — same victims as the ordered layout."""
+    _run([("roco", 500)], L=2, Hq=4, H=4, D=128, budget=160, seed=41, heavy=True)
+    _run([("roco", 60)], L=2, Hq=8, H=4, D=128, budget=2400, seed=42, heavy=True)
 
 
 def test_extents_beyond_2304_rows():
