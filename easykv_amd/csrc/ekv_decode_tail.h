@@ -382,12 +382,30 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
         if (tid < 8) s_hist[256 + tid] = 0;    // [256] members listed so far, [257] bin, [258] below, [260..261] result
         red.min2_u32(kmin, nmax);              // (its barrier also publishes the zeroed histogram)
         const uint32_t kmax = ~nmax;
-        if (kmin <= kmax) {
-          const uint32_t range = kmax - kmin;
+        // Up to three levels: when the threshold bin holds more members than the list (broad score distributions: a dense cluster
+        // of stds inside a range that a few outliers stretch — 563 members in the median head after 9 k steps on keys with log-normal
+        // norms, and the 32-pass bisection below ran in 3 heads of 4), the histogram is repeated over THAT bin's key range with the
+        // rank reduced by what lies below it.  The sentinel bin (1e9, NaN) cannot be refined by key: it falls through.
+        uint32_t lo = kmin, hi = kmax, k_rem = (uint32_t)sc.roco_k1, below_acc = 0;
+        for (int level = 0; level < 3 && thr == 0 && lo <= hi; ++level) {
+          const uint32_t range = hi - lo;
           const int shift = range < 256u ? 0 : 24 - __clz(range);     // range >> shift < 256
-          auto bin_of = [&](uint32_t k) { return k >= kSent ? 255u : min(255u, (k - kmin) >> shift); };
+          // 256 = not in this level's range (level 0: every key is, the sentinels in bin 255)
+          auto bin_of = [&](uint32_t k) {
+            if (level == 0) return k >= kSent ? 255u : min(255u, (k - lo) >> shift);
+            return (k < lo || k > hi) ? 256u : min(255u, (k - lo) >> shift);
+          };
+          if (level > 0) {
+            __syncthreads();                     // (everybody has read the previous level's header)
+            if (tid < 256) s_hist[tid] = 0;
+            if (tid < 8) s_hist[256 + tid] = 0;
+            __syncthreads();
+          }
   #pragma unroll 4
-          for (int j = tid; j < W; j += NT) atomicAdd(&s_hist[bin_of(kstd[j])], 1u);
+          for (int j = tid; j < W; j += NT) {
+            const uint32_t bn = bin_of(kstd[j]);
+            if (bn < 256u) atomicAdd(&s_hist[bn], 1u);
+          }
           __syncthreads();
           if (tid < 64) {                      // wave 0: lane l owns bins 4l .. 4l+3; inclusive scan over the lanes
             const uint32_t c0 = s_hist[4 * tid], c1 = s_hist[4 * tid + 1], c2 = s_hist[4 * tid + 2], c3 = s_hist[4 * tid + 3];
@@ -398,8 +416,8 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
               const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
               if (tid >= o) incl += up;
             }
-            const uint32_t excl = incl - mine, k1 = (uint32_t)sc.roco_k1;
-            if (excl < k1 && k1 <= incl) {     // exactly one lane: the bin where the cumulative count reaches k1
+            const uint32_t excl = incl - mine, k1 = k_rem;
+            if (excl < k1 && k1 <= incl) {     // exactly one lane: the bin where the cumulative count reaches the rank
               uint32_t below = excl, b = 4 * tid;
               if (below + c0 < k1) { below += c0; ++b;
                 if (below + c1 < k1) { below += c1; ++b;
@@ -421,11 +439,18 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
               const unsigned long long e = s_list[tid];
               uint32_t rank = 0;
               for (int i = 0; i < (int)in_bin; ++i) rank += s_list[i] < e ? 1u : 0u;
-              if (below + rank == (uint32_t)sc.roco_k1 - 1u) *reinterpret_cast<unsigned long long*>(s_hist + 260) = e + 1ull;
+              if (below_acc + below + rank == (uint32_t)sc.roco_k1 - 1u) *reinterpret_cast<unsigned long long*>(s_hist + 260) = e + 1ull;
             }
             __syncthreads();
             thr = *reinterpret_cast<const unsigned long long*>(s_hist + 260);
+            break;
           }
+          if ((level == 0 && b_sel == 255u) || shift == 0) break;      // sentinels / one key value: not a matter of key ranges
+          below_acc += below;
+          k_rem -= below;
+          const uint32_t nlo = lo + (b_sel << shift);
+          hi = b_sel == 255u ? hi : min(hi, nlo + ((1u << shift) - 1u));
+          lo = nlo;
         }
       }
       if (thr == 0) {
