@@ -126,91 +126,6 @@ __device__ __forceinline__ void ekv_tail_prefetch_rows(const EkvScoreArgs& sc, s
   if (RAGGED) ekv_tail_prefetch_ragged<NW>(sc, head_row, W, roco, sS, sQ, sC, with_cnt);
 }
 
-// Exclusive threshold on unique 64-bit composites such that exactly k of the workgroup's live composites lie below it, or 0 when a bin
-// is too crowded to list (the caller's bisection then runs).  comp(it) = composite of the thread's it-th column (column tid + it * NT),
-// bit it of livem = the column counts.  Bins are cut at 64 sampled composites (every (E / 64)-th column that is live; ordered by
-// wave 0 with 64 readlane compares): five barriers — sample, pivots, histogram, bin of rank k - 1, its members ranked.
-template <int ITEMS, int NW, typename C>
-__device__ __forceinline__ unsigned long long ekv_pivot_threshold(RedN<NW>& red, C comp, unsigned livem, int E, int k, uint32_t* hist,
-                                                                  unsigned long long* list, int list_cap) {
-  constexpr int NT = 64 * NW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long* piv = reinterpret_cast<unsigned long long*>(hist + 128);   // 64 pivots in the upper half of the 264 words
-  const int step = max(E / 64, 1);
-  if (k < 1) return 0;
-  (void)red;
-  for (int i = tid; i < 128; i += NT) hist[i] = 0;          // [0..64] bins, [66] listed, [67] bin, [68] below, [70..71] result
-  if (tid < 64) piv[tid] = ~0ull - (unsigned long long)(63 - tid);      // (a sample position without a live entry: distinct maxima)
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int j = tid + it * NT;
-    if (((livem >> it) & 1u) && j % step == 0 && j / step < 64) piv[j / step] = comp(it);
-  }
-  __syncthreads();
-  if (wave == 0) {               // order the 64 samples: rank by counting (unique values), lane -> piv[rank]
-    const unsigned long long mine = piv[lane];
-    int rank = 0;
-    for (int x = 0; x < 64; ++x) {
-      const unsigned long long other = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), x) << 32) |
-                                       (uint32_t)__builtin_amdgcn_readlane((int)(mine & 0xFFFFFFFFu), x);
-      rank += other < mine ? 1 : 0;
-    }
-    piv[rank] = mine;
-  }
-  __syncthreads();
-  int bin[ITEMS];                // bin = number of pivots <= composite, 0 .. 64
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const unsigned long long c = comp(it);
-    int bb = 0;
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) bb += piv[bb + sft - 1] <= c ? sft : 0;
-    bb += piv[bb] <= c ? 1 : 0;
-    bin[it] = bb;
-    if ((livem >> it) & 1u) atomicAdd(&hist[bb], 1u);
-  }
-  __syncthreads();
-  if (wave == 0) {               // lane l owns bin l (lane 63 also bin 64); inclusive scan
-    const uint32_t mine = hist[lane];
-    uint32_t incl = mine;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    const uint32_t excl = incl - mine, kk = (uint32_t)k;
-    if (excl < kk && kk <= incl) {
-      hist[67] = lane;
-      hist[68] = excl;
-    }
-    if (lane == 63 && kk > incl) {
-      hist[67] = 64;
-      hist[68] = incl;
-    }
-  }
-  __syncthreads();
-  const int b_sel = (int)hist[67];
-  const uint32_t below = hist[68], in_bin = hist[b_sel];
-  if ((int)in_bin > list_cap || (int)in_bin > NT) {
-    __syncthreads();
-    return 0;
-  }
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it)
-    if (bin[it] == b_sel && ((livem >> it) & 1u)) list[atomicAdd(&hist[66], 1u)] = comp(it);
-  __syncthreads();
-  if (tid < (int)in_bin) {
-    const unsigned long long e = list[tid];
-    uint32_t rank = 0;
-    for (int i = 0; i < (int)in_bin; ++i) rank += list[i] < e ? 1u : 0u;
-    if (below + rank == (uint32_t)k - 1u) *reinterpret_cast<unsigned long long*>(hist + 70) = e + 1ull;
-  }
-  __syncthreads();
-  const unsigned long long thr = *reinterpret_cast<const unsigned long long*>(hist + 70);
-  __syncthreads();               // (before the caller reuses the scratch: [256..263] of the warm path / the victim row)
-  return thr;
-}
-
 // PHYS: s_logit is indexed by PHYSICAL row (the fused kernel streamed the rows in address order); the logit of position
 // j sits at s_logit[slot_of_pos[j]].  The passes below still run in position order with the same thread <-> column
 // mapping, so sums are formed in exactly the order of the position-indexed variant (bit-identical scores).
@@ -749,13 +664,80 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
         if (tid == 0) s_hist[256] = 0;
       }
     }
-    // Full select (no hint yet, or the window missed): bins cut at 64 SAMPLED composites instead of 256 bins of equal key width — the
-    // width histogram piles most keys into a few bins as soon as the stds spread over decades (keys with log-normal norms: its
-    // threshold bin overflowed the candidate list and the 32-pass bisection below ran: 190 -> 206 us per step within 8 k steps, ordered
-    // layout) —, about E / 64 members per bin whatever the distribution.  Same scheme as lds_kth_threshold (ekv_chunk_lds.inc).
-    if (thr == 0) thr = ekv_pivot_threshold<ITEMS, NW>(red, [&](int it) { return comp(it); }, livem, E, sc.roco_k1, s_hist, s_list, list_cap);
-    (void)kmin;
-    (void)nmax;
+    // Full select (no hint yet, or the window missed): 256 bins of equal key width over the range of the real keys, the bin holding
+    // rank k1 - 1, its members ranked — and when that bin holds more members than the list (broad score distributions: a dense cluster
+    // of stds inside a range a few outliers stretch), the histogram again over THAT bin's key range, up to three levels (see the
+    // ordered tail).  (Bins cut at 64 sampled composites — ekv_pivot_threshold — were equally robust, 195 -> 189.5 us on keys with
+    // log-normal norms, but cost i.i.d. keys 1-3 us while a fresh state settles: every miss paid the pivot ordering and seven-step
+    // searches.)
+    if (thr == 0) {
+      if (tid < 4) s_hist[256 + tid] = 0;    // (bins [0, 256) are still zero from the top of the tail; [260..262]: the result and the victim row stay)
+      red.min2_u32(kmin, nmax);              // (its barrier also publishes the zeroed counters)
+      const uint32_t kmax = ~nmax;
+      uint32_t lo = kmin, hi = kmax, k_rem = (uint32_t)sc.roco_k1, below_acc = 0;
+      for (int level = 0; level < 3 && thr == 0 && lo <= hi; ++level) {
+        const uint32_t range = hi - lo;
+        const int shift = range < 256u ? 0 : 24 - __clz(range);
+        auto bin_of = [&](uint32_t k) {      // 256 = not in this level's range (level 0: every live key is, the sentinels in bin 255)
+          if (level == 0) return k >= kSent ? 255u : min(255u, (k - lo) >> shift);
+          return (k < lo || k > hi) ? 256u : min(255u, (k - lo) >> shift);
+        };
+        if (level > 0) {
+          __syncthreads();                   // (everybody has read the previous level's header)
+          if (tid < 256) s_hist[tid] = 0;
+          if (tid < 4) s_hist[256 + tid] = 0;
+          __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+          const uint32_t bn = lives(it) ? bin_of(kstd[it]) : 256u;
+          if (bn < 256u) atomicAdd(&s_hist[bn], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+          const uint32_t c0 = s_hist[4 * tid], c1 = s_hist[4 * tid + 1], c2 = s_hist[4 * tid + 2], c3 = s_hist[4 * tid + 3];
+          uint32_t incl = c0 + c1 + c2 + c3;
+          const uint32_t mine = incl;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (tid >= o) incl += up;
+          }
+          const uint32_t excl = incl - mine, k1 = k_rem;
+          if (excl < k1 && k1 <= incl) {
+            uint32_t below = excl, bb = 4 * tid;
+            if (below + c0 < k1) { below += c0; ++bb;
+              if (below + c1 < k1) { below += c1; ++bb;
+                if (below + c2 < k1) { below += c2; ++bb; } } }
+            s_hist[257] = bb;
+            s_hist[258] = below;
+          }
+        }
+        __syncthreads();
+        const uint32_t b_sel = s_hist[257], below = s_hist[258], in_bin = s_hist[b_sel];
+        if ((int)in_bin <= list_cap && (int)in_bin <= NT) {
+#pragma unroll
+          for (int it = 0; it < ITEMS; ++it)
+            if (lives(it) && bin_of(kstd[it]) == b_sel) s_list[atomicAdd(&s_hist[256], 1u)] = comp(it);
+          __syncthreads();
+          if (tid < (int)in_bin) {
+            const unsigned long long e = s_list[tid];
+            uint32_t rank = 0;
+            for (int i = 0; i < (int)in_bin; ++i) rank += s_list[i] < e ? 1u : 0u;
+            if (below_acc + below + rank == (uint32_t)sc.roco_k1 - 1u) *reinterpret_cast<unsigned long long*>(s_hist + 260) = e + 1ull;
+          }
+          __syncthreads();
+          thr = *reinterpret_cast<const unsigned long long*>(s_hist + 260);
+          break;
+        }
+        if ((level == 0 && b_sel == 255u) || shift == 0) break;
+        below_acc += below;
+        k_rem -= below;
+        const uint32_t nlo = lo + (b_sel << shift);
+        hi = b_sel == 255u ? hi : min(hi, nlo + ((1u << shift) - 1u));
+        lo = nlo;
+      }
+    }
     if (thr == 0) {      // fallback: bitwise bisection on the keys, ties at the threshold to the lower births
       uint32_t tau = 0;
       for (int bit = 31; bit >= 0; --bit) {
