@@ -279,7 +279,7 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
     // Chunk steps (two or three workgroups per CU): a split costs a partial per query row and split, a fold in the scorer and a
     // shorter stream per workgroup, so the grid is filled to the 256..512 workgroups that are resident at a time — not to 1024:
     // the fewest splits (powers of two, <= 8) that give every CU a workgroup, doubled once more if a split then still streams
-    // >= 1024 rows.  Measured (us per step, MI355X, round 3, scratch/split_sweep.py; this rule / what the 1024- or 3072-target picked):
+    // >= 1024 rows.  Measured (us per step, MI355X, round 3 sweep; this rule / what the 1024- or 3072-target picked):
     //   wide kernel, 8 KV heads x 1 layer, 64 rows, T = 1248 / 2176 / 5098:  46.7 / 54.7 / 76.2   (50.0 / 61.4 / 84.8)
     //   wide kernel, 32 heads x 1 layer, 96 rows:                            63.9 / 76.6 / 110.5  (69.6 / 91.6 / 155.9)
     //   wide kernel, 128 (head, layer) pairs, 96 rows:                       97.8 / 110.8 / 182.0 (108.6 / 132.5 / 208.6)

@@ -1,0 +1,33 @@
+"""Per-layer decode (one layer per call + deferred scorer), headline shape; warmed; one lib per process."""
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from easykv_amd import KVBank, StepPlan
+dev = torch.device("cuda")
+def run(policy="roco", L=32, Hq=32, H=32, D=128, budget=2048, flush=True):
+    T = budget + 1
+    g = torch.Generator(device=dev).manual_seed(5)
+    bank = KVBank(L, Hq, H, D, cap=T + 63, device=dev)
+    bank.load_rows(torch.randn(L, H, budget, D, generator=g, device=dev).half(), torch.randn(L, H, budget, D, generator=g, device=dev).half())
+    bank.slot_of_pos[:, :, :budget] = torch.argsort(torch.rand(L, H, budget, generator=g, device=dev), dim=-1).int()
+    bank.state_init(T, 0)
+    n_in = 8
+    qs = torch.randn(n_in, L, Hq, 1, D, generator=g, device=dev).half(); ks = torch.randn(n_in, L, H, 1, D, generator=g, device=dev).half(); vs = torch.randn(n_in, L, H, 1, D, generator=g, device=dev).half()
+    o = torch.empty(L, Hq, 1, D, dtype=torch.float16, device=dev)
+    plan = StepPlan(policy=policy, phase="decode", evict=True, score_off=0, budget=budget)
+    views = [[(qs[i, l:l + 1], ks[i, l:l + 1], vs[i, l:l + 1], o[l:l + 1]) for l in range(L)] for i in range(n_in)]
+    res = []
+    for blk in range(3):
+        n, t0 = 0, time.perf_counter()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]; e[0].record()
+        while True:
+            for _ in range(8):
+                for l in range(L):
+                    q1, k1, v1, o1 = views[n % n_in][l]
+                    bank.attend(plan, q1, k1, v1, layer_begin=l, out=o1, defer=True)
+                bank.flush(); n += 1
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 > 0.4: break
+        e[1].record(); torch.cuda.synchronize()
+        res.append((round(e[0].elapsed_time(e[1]) / n / L * 1e3, 2), round((time.perf_counter() - t0) / n / L * 1e6, 2)))
+    return res
+print(os.path.basename(os.environ.get("EASYKV_HIP_LIB", "default")), "us/layer (events, wall):", run(), flush=True)
