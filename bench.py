@@ -107,7 +107,7 @@ def cpu_baseline(args, budget, policy, seconds=10.0):
 
     ncpu = min(16, os.cpu_count() or 1)
     v0, n0, ls0, e0 = run(ncpu, False, seconds)
-    out = dict(value=v0, unit="tokens/s", cores=ncpu, kind="port", cpu=_cpu_model(), host_threads_available=os.cpu_count(),
+    out = dict(value=v0, unit="tokens/s", cores=ncpu, kind="port", kind_detail=f"port (the oracle), {ncpu} threads — the all-core variant SURVEY.md §8d names is in `variants`", cpu=_cpu_model(), host_threads_available=os.cpu_count(),
                sample=f"{n0} whole decode tokens x {L} layers ({ls0} layer-steps, {e0:.1f} s) at full T={T}, H={H}, D={D}, fp32 state, "
                       f"{policy}, reference-shaped (torch.cat append, topk, boolean-mask compaction)")
     variants = []
@@ -254,7 +254,9 @@ def prefill_pipeline(args, dev, rank, world, DS, S=9994, stride=96, n_chunks=32,
     Hq, D = args.heads, args.head_dim
     H = args.kv_heads or Hq
     shard = DS.LayerShard(rank, world, args.layers)
-    L = shard.count
+    Ls = shard.count
+    k = seqs_per_launch(max(1, args.layers // world), H, args.seqs_per_launch)      # in-flight sequences (prompts) whose chunk steps share a launch; one value for the job
+    L = Ls * k
     bp, idx, _ = geometry("encoding", S, 0.5, stride)
     g = torch.Generator(device=dev).manual_seed(4321 + rank)
     rnd = lambda h, n: torch.randn(L, h, n, D, generator=g, device=dev).half()
@@ -268,7 +270,7 @@ def prefill_pipeline(args, dev, rank, world, DS, S=9994, stride=96, n_chunks=32,
     outs = [torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev) for _ in range(4)]     # (posted outputs stay alive)
     ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
     stage = DS.PipelineStage(shard, depth=2)
-    like = torch.zeros(1, stride, Hq * D, dtype=torch.float16, device=dev)
+    like = torch.zeros(k, stride, Hq * D, dtype=torch.float16, device=dev)
     t0 = 0.0
     for i in range(n_in):
         if i == warm:
@@ -278,14 +280,15 @@ def prefill_pipeline(args, dev, rank, world, DS, S=9994, stride=96, n_chunks=32,
         stage.recv_hidden(like)                    # the previous stage's output of THIS chunk (first stage: nothing to wait for)
         out = outs[i % 4]
         bank.attend(plan, qs_[i], ks_[i], vs_[i], out=out, evict_ids=ids)
-        stage.send_hidden(out[L - 1].transpose(0, 1).reshape(1, stride, Hq * D))      # posted; this stage carries on with chunk i+1
+        # posted; this stage carries on with chunk i+1 (the output of every sequence's last layer on this rank)
+        stage.send_hidden(out.view(k, Ls, Hq, stride, D)[:, Ls - 1].transpose(1, 2).reshape(k, stride, Hq * D))
     stage.drain()
     DS.barrier(dev)
     dt = DS.max_over_ranks(time.perf_counter() - t0, dev)
     return {"workload": f"bench-P chunk phase through the layer pipeline: S={S} stride={stride} budget=0.5 (configs[3] shape), {args.layers} layers over "
-                        f"{world} ranks ({L} on rank {rank}), T={idx + stride}, Hq={Hq} H={H} D={D} roco",
-            "value": n_chunks * stride / dt, "unit": "prompt tokens/s (chunk phase, attention/eviction path only, all stages)",
-            "us_per_chunk_step_pipeline": dt / n_chunks * 1e6, "chunks_timed": n_chunks,
+                        f"{world} ranks ({Ls} on rank {rank}, {k} sequence(s) per launch), T={idx + stride}, Hq={Hq} H={H} D={D} roco",
+            "value": k * n_chunks * stride / dt, "unit": "prompt tokens/s (chunk phase, attention/eviction path only, all stages)",
+            "us_per_chunk_step_pipeline": dt / n_chunks * 1e6, "chunks_timed": n_chunks, "sequences_per_launch": k,
             "handoff": "isend of the stage output, up to 2 in flight; recv blocking", "max_outputs_in_flight_rank0": max(stage.run_ahead or [0])}
 
 
@@ -526,22 +529,71 @@ def streaming_decode(args, dev, budget, policy):
                          "note": "algorithmic bytes exclude the rotation tables (L2-resident)"}}
 
 
+def seqs_per_launch(n_layers_of_rank, n_kv_heads, want=0):
+    """In-flight sequences a pipeline stage serves per launch.  A stage that owns few layers launches few heads (N = 8: 4 layers x 32
+    = 128 heads, half a head per CU: the fused one-launch step needs >= 256, ekv_abi.hip) — but the pipeline holds >= N sequences in
+    flight anyway, and the bank is generic in its layer count: (sequence, layer) pairs are just more layers.  Default:
+    the fewest sequences (1, 2, 4 ...) that put >= 256 heads into the launch."""
+    if want > 0:
+        return want
+    k = 1
+    while k * n_layers_of_rank * n_kv_heads < 256 and k < 8:
+        k *= 2
+    return k
+
+
+def decode_config0(args, dev, P=37, budget=200, n=512):
+    """BASELINE.json configs[0] at its own geometry (test_decoding.py:29-48: decoding mode, budget 200, roco; the reference runs it on
+    the CPU in fp32): the decode step after the budget has filled — a prompt of P never-evicted tokens + W = 201 scored slots,
+    recent window 60, k1 = 140 — all 32 layers in one launch.  A 4 MB-per-layer step: launch- and tail-bound, not a bandwidth figure."""
+    from easykv_amd import KVBank, StepPlan
+    L, Hq, D = args.layers, args.heads, args.head_dim
+    H = args.kv_heads or Hq
+    T = P + budget + 1
+    gen = torch.Generator(device=dev).manual_seed(200)
+    bank = KVBank(L, Hq, H, D, cap=T + 8, device=dev)
+    bank.load_rows(torch.randn(L, H, P + budget, D, generator=gen, device=dev).half(), torch.randn(L, H, P + budget, D, generator=gen, device=dev).half())
+    bank.state_init(budget + 1, 0)
+    n_in = 32
+    qs = torch.randn(n_in, L, Hq, 1, D, generator=gen, device=dev).half()
+    ks = torch.randn(n_in, L, H, 1, D, generator=gen, device=dev).half()
+    vs = torch.randn(n_in, L, H, 1, D, generator=gen, device=dev).half()
+    o = torch.empty(L, Hq, 1, D, dtype=torch.float16, device=dev)
+    ids = torch.empty(L, H, 1, dtype=torch.int32, device=dev)
+    plan = StepPlan(policy="roco", phase="decode", evict=True, score_off=P, budget=budget)
+    n_split, fused = bank.step_plan(plan, 1)
+    for i in range(256):
+        bank.attend(plan, qs[i % n_in], ks[i % n_in], vs[i % n_in], out=o, evict_ids=ids)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for i in range(n):
+        bank.attend(plan, qs[i % n_in], ks[i % n_in], vs[i % n_in], out=o, evict_ids=ids)
+    ev[1].record()
+    torch.cuda.synchronize(dev)
+    t = ev[0].elapsed_time(ev[1]) / n * 1e-3
+    by = 2 * H * T * D * 2 + 2 * Hq * D * 2 + 2 * H * D * 2 + 2 * 3 * H * (budget + 1) * 4      # W_step of §8d with the score rows over W = budget + 1
+    return {"workload": f"configs[0] decode step: decoding mode, budget={budget}, prompt {P}, T={T}, W={budget + 1}, L={L} Hq={Hq} H={H} D={D} roco",
+            "us_per_step": t * 1e6, "value": 1.0 / t, "unit": "tokens/s", "plan": {"fused_one_launch": bool(fused), "n_split": n_split},
+            "roofline": {"bound": "hbm", "achieved": by * L / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by * L / t / 1e9 / HBM_PEAK_GBS, "bytes_per_step": by * L}}
+
+
 def stage_workloads(args, dev, budget, policy):
     """Secondary figures: what ONE RANK of the layer-sharded model runs per step at N = 2 / 4 / 8 (strong scaling) —
-    the Bench-D decode step with 16 / 8 / 4 of the 32 layers in one launch — measured on this one GPU so that the first real 1/2/4/8
+    the Bench-D decode step with 16 / 8 / 4 of the 32 layers per sequence — measured on this one GPU so that the first real 1/2/4/8
     curve can be checked against a prediction: us per step, the library's plan (one fused launch or attention +
-    scorer launches, key-range splits), the roofline fraction on the algorithmic bytes of those layers.  Same steady-state
-    preparation as the headline run (scattered slot map, pre-warmed score rows).  Plus the configs[3] chunk step with 4 layers."""
+    scorer launches, key-range splits), the roofline fraction on the algorithmic bytes of the launch.  A stage with fewer than 256
+    heads serves `sequences_per_launch` in-flight sequences per launch (seqs_per_launch above; round 5) — the single-sequence
+    launch of the same stage is reported beside it.  Same steady-state preparation as the headline run (scattered slot map,
+    pre-warmed score rows).  Plus the configs[3] chunk step of a 4-layer stage."""
     from easykv_amd import KVBank, StepPlan, geometry
     Hq, D = args.heads, args.head_dim
     H = args.kv_heads or Hq
     T = budget + 1
     n_state = {"roco": 3, "h2o_head": 1, "tova": 1}.get(policy, 0)
     b = algorithmic_bytes(H, Hq, D, T, 1, n_state)
-    out = []
-    for L in (16, 8, 4):
-        if L >= args.layers:
-            continue
+
+    def decode_stage(Ls, k):
+        L = Ls * k                                      # (sequence, layer) pairs in the launch
         gen = torch.Generator(device=dev).manual_seed(77 + L)
         bank = KVBank(L, Hq, H, D, cap=T + 63, device=dev)
         bank.load_rows(torch.randn(L, H, budget, D, generator=gen, device=dev).half(), torch.randn(L, H, budget, D, generator=gen, device=dev).half())
@@ -571,47 +623,71 @@ def stage_workloads(args, dev, budget, policy):
             bank.attend(plan, qs[(i + j) % n_in], ks[(i + j) % n_in], vs[(i + j) % n_in], out=o, evict_ids=ids)
         ev[1].record()
         torch.cuda.synchronize(dev)
-        t = ev[0].elapsed_time(ev[1]) / n * 1e-3
-        gbs = b["total"] * L / t / 1e9
-        out.append({"workload": f"decode step of a {L}-layer stage (one rank of N={args.layers // L}, strong scaling): L={L} Hq={Hq} H={H} D={D} T={T} {policy}",
-                    "layers_in_launch": L, "us_per_step": t * 1e6, "plan": {"fused_one_launch": bool(fused), "n_split": n_split},
-                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "bytes_per_step": b["total"] * L, "timing": "one HIP event pair around 512 back-to-back steps"},
-                    "predicted_pipeline_tokens_per_s": 1.0 / t})
         del bank
+        return ev[0].elapsed_time(ev[1]) / n * 1e-3, n_split, fused
+
+    out = []
+    for Ls in (16, 8, 4):
+        if Ls >= args.layers:
+            continue
+        k = seqs_per_launch(Ls, H)
+        t, n_split, fused = decode_stage(Ls, k)
+        gbs = b["total"] * Ls * k / t / 1e9
+        e = {"workload": f"decode step of a {Ls}-layer stage (one rank of N={args.layers // Ls}, strong scaling), {k} in-flight sequence(s) per launch: "
+                         f"L={Ls} Hq={Hq} H={H} D={D} T={T} {policy}",
+             "layers_in_launch": Ls * k, "layers_of_stage": Ls, "sequences_per_launch": k, "us_per_step": t * 1e6, "plan": {"fused_one_launch": bool(fused), "n_split": n_split},
+             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                          "bytes_per_step": b["total"] * Ls * k, "timing": "one HIP event pair around 512 back-to-back steps"},
+             "predicted_pipeline_tokens_per_s": k / t}
+        if k > 1:       # the same stage serving ONE sequence per launch (rounds 1-4)
+            t1, ns1, fu1 = decode_stage(Ls, 1)
+            e["single_sequence_launch"] = {"us_per_step": t1 * 1e6, "frac": b["total"] * Ls / t1 / 1e9 / HBM_PEAK_GBS, "plan": {"fused_one_launch": bool(fu1), "n_split": ns1},
+                                           "predicted_pipeline_tokens_per_s": 1.0 / t1}
+        out.append(e)
     # the configs[3] chunk step of a 4-layer stage (N = 8)
-    S, stride, L = 9994, 96, 4
-    if L < args.layers:
+    S, stride, Ls = 9994, 96, 4
+    if Ls < args.layers:
         bp, idx, _ = geometry("encoding", S, 0.5, stride)
-        gen = torch.Generator(device=dev).manual_seed(4321)
-        rnd = lambda h, m: torch.randn(L, h, m, D, generator=gen, device=dev).half()
-        bank = KVBank(L, Hq, H, D, cap=idx + stride, device=dev)
-        bank.load_rows(rnd(H, idx), rnd(H, idx))
-        bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=gen, device=dev), dim=-1).int()
-        bank.state_init(idx + stride, 2, stride)
-        plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=bp, recent=int(bp * 0.1), sink=4, stride=stride)
-        ins = [(rnd(Hq, stride), rnd(H, stride), rnd(H, stride)) for _ in range(4)]
-        o = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
-        ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
-        n_split, fused = bank.step_plan(plan, stride)
-        for j in range(24):
-            bank.attend(plan, *ins[j % 4], out=o, evict_ids=ids)
-        n = 48
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        ev[0].record()
-        for j in range(n):
-            bank.attend(plan, *ins[j % 4], out=o, evict_ids=ids)
-        ev[1].record()
-        torch.cuda.synchronize(dev)
-        t = ev[0].elapsed_time(ev[1]) / n * 1e-3
         by = algorithmic_bytes(H, Hq, D, idx + stride, stride, 3)
-        gbs = by["total"] * L / t / 1e9
-        out.append({"workload": f"configs[3] chunk step of a 4-layer stage (one rank of N=8): S={S} stride={stride} T={idx + stride} L={L} Hq={Hq} H={H} D={D} roco",
-                    "layers_in_launch": L, "us_per_step": t * 1e6, "plan": {"fused_one_launch": bool(fused), "n_split": n_split},
-                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "bytes_per_step": by["total"] * L},
-                    "predicted_pipeline_prompt_tokens_per_s": stride / t})
-        del bank
+
+        def chunk_stage(k):
+            L = Ls * k
+            gen = torch.Generator(device=dev).manual_seed(4321)
+            rnd = lambda h, m: torch.randn(L, h, m, D, generator=gen, device=dev).half()
+            bank = KVBank(L, Hq, H, D, cap=idx + stride, device=dev)
+            bank.load_rows(rnd(H, idx), rnd(H, idx))
+            bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=gen, device=dev), dim=-1).int()
+            bank.state_init(idx + stride, 2, stride)
+            plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=bp, recent=int(bp * 0.1), sink=4, stride=stride)
+            ins = [(rnd(Hq, stride), rnd(H, stride), rnd(H, stride)) for _ in range(4)]
+            o = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
+            ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
+            n_split, fused = bank.step_plan(plan, stride)
+            for j in range(24):
+                bank.attend(plan, *ins[j % 4], out=o, evict_ids=ids)
+            n = 48
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            for j in range(n):
+                bank.attend(plan, *ins[j % 4], out=o, evict_ids=ids)
+            ev[1].record()
+            torch.cuda.synchronize(dev)
+            del bank
+            return ev[0].elapsed_time(ev[1]) / n * 1e-3, n_split, fused
+
+        k = seqs_per_launch(Ls, H)
+        t, n_split, fused = chunk_stage(k)
+        gbs = by["total"] * Ls * k / t / 1e9
+        e = {"workload": f"configs[3] chunk step of a 4-layer stage (one rank of N=8), {k} in-flight sequence(s) per launch: S={S} stride={stride} T={idx + stride} "
+                         f"L={Ls} Hq={Hq} H={H} D={D} roco",
+             "layers_in_launch": Ls * k, "layers_of_stage": Ls, "sequences_per_launch": k, "us_per_step": t * 1e6, "plan": {"fused_one_launch": bool(fused), "n_split": n_split},
+             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                          "bytes_per_step": by["total"] * Ls * k},
+             "predicted_pipeline_prompt_tokens_per_s": k * stride / t}
+        if k > 1:
+            t1, ns1, fu1 = chunk_stage(1)
+            e["single_sequence_launch"] = {"us_per_step": t1 * 1e6, "frac": by["total"] * Ls / t1 / 1e9 / HBM_PEAK_GBS, "plan": {"fused_one_launch": bool(fu1), "n_split": ns1}}
+        out.append(e)
     return out
 
 
@@ -672,7 +748,10 @@ def decode_run(args, dev, rank, world, scaling, DS, want_seq):
     H = args.kv_heads or Hq
     T = budget + 1
     shard = DS.LayerShard(rank, world, args.layers if scaling == "strong" else args.layers * world)
-    L = shard.count                     # layers of this rank
+    Ls = shard.count                    # layers of this rank
+    # in-flight sequences this stage serves per launch (seqs_per_launch): 1 unless the stage launches < 256 heads (N = 8)
+    k = seqs_per_launch(max(1, args.layers // world) if scaling == "strong" else args.layers, H, args.seqs_per_launch)      # (one value for the whole job)
+    L = Ls * k                          # (sequence, layer) pairs of this rank's bank: pair s * Ls + l
     n_total = args.steps + args.warmup
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     bank = KVBank(L, Hq, H, D, cap=T + 63, device=dev)
@@ -694,7 +773,8 @@ def decode_run(args, dev, rank, world, scaling, DS, want_seq):
     # two output buffers in turn: the stage output of step i (the attention output of the rank's LAST layer) is sent straight
     # from outs[i % 2] while step i + 1 writes the other one
     outs = [torch.empty(L, Hq, 1, D, dtype=torch.float16, device=dev) for _ in range(2)]
-    hidden_in = [torch.zeros(1, Hq * D, dtype=torch.float16, device=dev) for _ in range(2)]
+    hidden_in = [torch.zeros(k, Hq * D, dtype=torch.float16, device=dev) for _ in range(2)]
+    hidden_out = [torch.zeros(k, Hq * D, dtype=torch.float16, device=dev) for _ in range(2)]
     ids = torch.empty(L, H, 1, dtype=torch.int32, device=dev)
     plan = StepPlan(policy=args.policy, phase="decode", evict=True, score_off=0, budget=budget, n_split=args.n_split)
     if args.policy == "recency":
@@ -742,7 +822,8 @@ def decode_run(args, dev, rank, world, scaling, DS, want_seq):
         if args.overlap_scorer and args.graph:
             bank.join()        # a captured step must end with every forked stream joined
         if handoff and handoff_on:   # pipeline hand-off of the stage output (north star)
-            send = out[L - 1].view(1, Hq * D)
+            # the stage output of every in-flight sequence: the attention output of its LAST layer on this rank
+            send = out[L - 1].view(1, Hq * D) if k == 1 else hidden_out[st["i"] & 1].copy_(out.view(k, Ls, Hq * D)[:, Ls - 1])
             if sync_handoff:
                 pending[:] = DS.ring_handoff_async(send, hidden_in[st["i"] & 1], shard, None)
             else:   # posted after this step's kernels, waited for after the next launch: the transfer overlaps it
@@ -826,7 +907,7 @@ def decode_run(args, dev, rank, world, scaling, DS, want_seq):
             seq = n_seq / (time.perf_counter() - ts)
     t_region = region[0].elapsed_time(region[1]) / args.steps * 1e-3
     return dict(elapsed=elapsed, t_region=t_region, ev=ev, per_step_events=per_step_events, n_split=n_split, fused=fused, lpl=lpl,
-                L=L, shard=shard, n_pre=n_pre, seq=seq, handoff=handoff_on, sync_handoff=sync_handoff, T=T, H=H, slot_rows=slot_rows)
+                L=L, Ls=Ls, k=k, rank_us=DS.all_gather_floats(t_region * 1e6, dev), shard=shard, n_pre=n_pre, seq=seq, handoff=handoff_on, sync_handoff=sync_handoff, T=T, H=H, slot_rows=slot_rows)
 
 
 def latest_pmc_summary(L, Hq, H, D, budget, policy, lpl):
@@ -889,6 +970,27 @@ def live_pmc(extra_args, kernel_substr, timeout_s=150, script=None):
             "2 x FETCH + WRITE (gfx950 correction, KiB -> bytes)")
 
 
+def respawn(args):
+    """Re-execute this command under torch.distributed.run, one rank per GPU of this node (backend nccl = RCCL; `--same-device
+    --backend gloo` puts every rank on cuda:0 for the 1-GPU test box).  Rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    if not args.same_device:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print(f"[bench] --gpus {args.gpus} asked for, {n_dev} GPU(s) visible: refusing to run fewer ranks under that label "
+                  "(--same-device --backend gloo runs every rank on cuda:0 for tests)", file=sys.stderr)
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / device-tensor sharing across processes needs it on this host driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -925,7 +1027,14 @@ def main():
     ap.add_argument("--identity-layout", action="store_true", help="start from a fresh bank's identity slot map (position order == "
                     "address order) instead of the scattered steady-state layout")
     ap.add_argument("--graph", action="store_true", help="capture one step (all launches) in a hipGraph and replay it")
+    ap.add_argument("--seqs-per-launch", type=int, default=0, help="in-flight sequences a rank serves per launch (0 = the fewest that put >= 256 heads "
+                    "into the launch: 1 up to N = 4, 2 at N = 8 for the Llama2-7B shape)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (it used to run ONE rank
+        # and label the line n_gpus = 1).  The reference's multi-GPU entry needs no launcher either (test_passkey.py:25-35).
+        sys.exit(respawn(args))
 
     from easykv_amd import dist as DS
     if args.ordered_rows:
@@ -935,21 +1044,24 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
     rank, local_rank, world = DS.init(args.backend)
     if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world} in the environment; the launcher's WORLD_SIZE is what runs (n_gpus = {world})", file=sys.stderr)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     if world > 1 and args.scaling == "strong" and args.layers < world:
         raise SystemExit("--scaling strong needs at least one layer per rank")
 
     Hq, D, budget = args.heads, args.head_dim, args.budget
+    # who is there: one all-reduce of ones over the backend (RCCL when nccl) and the device every rank runs on
+    ranks_seen = int(round(DS.sum_over_ranks(1.0, dev)))
+    devices = [int(x) for x in DS.all_gather_floats(float(dev.index or 0), dev)]
     r = decode_run(args, dev, rank, world, args.scaling, DS, want_seq=(rank == 0 and world == 1))
     second = None
     if world > 1 and not args.no_second_scaling and not args.graph:
         other = "weak" if args.scaling == "strong" else "strong"
         r2 = decode_run(args, dev, rank, world, other, DS, want_seq=False)
-        tokens2 = args.steps * (world if other == "weak" else 1)
+        tokens2 = args.steps * r2["k"] * (world if other == "weak" else 1)
         second = {"scaling": other, "value": tokens2 / r2["elapsed"], "unit": "tokens/s", "ms_per_step": r2["elapsed"] / args.steps * 1e3,
-                  "layers_per_rank": r2["L"], "fused": r2["fused"], "n_split": r2["n_split"],
+                  "layers_per_rank": r2["Ls"], "sequences_per_launch": r2["k"], "fused": r2["fused"], "n_split": r2["n_split"],
                   "note": "weak: every rank owns a whole 32-layer block (aggregate layer-parallel throughput)" if other == "weak" else
                           "strong: the 32-layer model split over the ranks"}
     pipe = None
@@ -962,12 +1074,15 @@ def main():
         lc0 = min(lpl, L)
         t_region, per_step_events = r["t_region"], r["per_step_events"]
         t_attn = t_region if not per_step_events else (1.0 if args.overlap_scorer else sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3)
-        tokens = args.steps * (world if args.scaling == "weak" else 1)
+        Ls, kseq = r["Ls"], r["k"]
+        # every step of a rank emits one token per in-flight sequence of its launch; strong: the pipeline's output is the last stage's
+        tokens = args.steps * kseq * (world if args.scaling == "weak" else 1)
         cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={args.layers} Hq={Hq} H={H} D={D} budget={budget} "
                            f"T={T} kv_policy={args.policy} (Llama2-7B shape, budget=50% of S=4096)",
-               "parallelism": (f"pp{world}: {args.layers} layers split into contiguous blocks, {L} per rank, point-to-point hand-off of the stage output"
-                               if args.scaling == "strong" else f"{world} x {L}-layer blocks, layer-parallel") if world > 1 else "1 GPU",
-               "layers_per_launch": lpl, "layers_per_rank": L, "layer_block_of_rank0": [r["shard"].begin, r["shard"].end], "n_split": r["n_split"],
+               "parallelism": (f"pp{world}: {args.layers} layers split into contiguous blocks, {Ls} per rank, point-to-point hand-off of the stage output"
+                               + (f", {kseq} in-flight sequences per launch ({Ls * kseq} (sequence, layer) pairs: >= 256 heads for the one-launch step)" if kseq > 1 else "")
+                               if args.scaling == "strong" else f"{world} x {Ls}-layer blocks, layer-parallel") if world > 1 else "1 GPU",
+               "layers_per_launch": lpl, "layers_per_rank": Ls, "sequences_per_launch": kseq, "layer_block_of_rank0": [r["shard"].begin, r["shard"].end], "n_split": r["n_split"],
                "fused": fused, "slot_map": "identity" if args.identity_layout else "scattered (random permutation: long-run steady state)",
                "score_rows": "slot-indexed (ABI 6: S / Q rewritten per step, count base + birth once per row, no compaction)" if r["slot_rows"] else "ordered",
 
@@ -978,6 +1093,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16 storage / f32 accumulate",
             "data": "synthetic", "config": cfg}
+        if world > 1:
+            line["ranks"] = {"backend": torch.distributed.get_backend(), "ranks_seen": ranks_seen, "devices": devices,
+                             "us_per_step": [round(x, 2) for x in r["rank_us"]]}
+            line["rccl_ranks_seen"] = ranks_seen if torch.distributed.get_backend() == "nccl" else 0
         if second is not None:
             line["second_scaling"] = second
         if pipe is not None:
@@ -1070,10 +1189,22 @@ def main():
             line["boundary_kernels"] = boundary_kernels(args, dev)
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(args, budget, args.policy if args.policy in ("roco", "h2o_head", "tova") else "roco")
+        if "strided_prefill_more" in line and (args.layers, Hq, H, D) == (32, 32, 32, 128):
+            # every BASELINE config in the part of the line a truncated tail keeps: one short entry each (details above)
+            c0 = decode_config0(args, dev)
+            line["decode_config0"] = c0
+            more, sp = line["strided_prefill_more"], line["strided_prefill"]
+            short = lambda i, name, e, us: {"config": i, "workload": name, "us_per_step": round(us, 1), "frac": round(e["roofline"]["frac"], 4),
+                                            "traffic_over_algorithmic": (round(e["roofline"]["traffic_over_algorithmic"], 3) if e["roofline"].get("traffic_over_algorithmic") else None)}
+            line["configs"] = [short(0, "decode step, budget 200, roco, 32 layers per launch (4 MB per layer: launch-bound)", c0, c0["us_per_step"]),
+                               short(1, "chunk step S=4096 stride 8 budget 0.5 roco (Llama2-7B shape)", sp, sp["us_per_chunk_step"]),
+                               short(2, "chunk step S=4096 stride 16 budget 0.3 (Mistral GQA 8 KV heads)", more[3], more[3]["us_per_chunk_step"]),
+                               short(3, "chunk step S=9994 stride 96 budget 0.5 roco (1 GPU: all 32 layers)", more[2], more[2]["us_per_chunk_step"]),
+                               short(4, "chunk step S=10253 stride 96 ppl geometry budget 4096, streaming RoPE-on-read (Llama2-13B heads, 40 layers)", more[4], more[4]["us_per_chunk_step"])]
         # Key order of the ONE line: the contract keys first, the bulky secondary figures in the middle, and what a reader of a
         # truncated tail must still see LAST — cpu_baseline, strided_prefill (BASELINE configs[1]) and roofline (the
         # driver's stdout tail had lost configs[1]).
-        tail_keys = [k for k in ("stage_workloads", "per_layer_launches", "cpu_baseline", "strided_prefill", "roofline_step", "roofline") if k in line]
+        tail_keys = [k for k in ("stage_workloads", "per_layer_launches", "cpu_baseline", "strided_prefill", "roofline_step", "roofline", "configs") if k in line]
         line = {**{k: v for k, v in line.items() if k not in tail_keys}, **{k: line[k] for k in tail_keys}}
         print(json.dumps(line))
     if world > 1:

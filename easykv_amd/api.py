@@ -147,12 +147,19 @@ class BudgetedKVCache:
             self._prefix_rule = (key, bool(info["two_pass"] and info["wide"]))
         return self._prefix_rule[1]
 
-    DEFER_WORKSPACE_LIMIT = 2 << 30      # bytes of logits / column sums of all layers a deferred chunk step may keep alive
+    DEFER_WORKSPACE_LIMIT = 1 << 30      # bytes of logits / column sums of all layers a deferred chunk step may keep alive ...
+    DEFER_WORKSPACE_FRACTION = 1 / 8     # ... and never more than this share of the device memory that is free when the rule is made
 
     def _defer_fits(self, plan, n) -> bool:
+        """Does this scored chunk step run with the scorers of all owned layers deferred to one launch per forward?  Not when the
+        immediate form is ONE launch already (the logits-in-LDS kernel, a chunk step with the scorer as its kernel tail — ekv_step_info
+        ``fused``: deferral would take the step off that kernel, whose arithmetic and speed differ), and not when every layer's logits /
+        column sums kept until the flush would pin too much HBM (one-pass shapes of long caches)."""
         key = (plan.policy, plan.accumulate, plan.evict, plan.two_pass, type(self.bank).default_two_pass, self.streaming, n, self.bank.n_slots[0])
         if getattr(self, "_defer_rule", (None, None))[0] != key:
-            self._defer_rule = (key, self.bank.deferred_workspace_bytes(plan, n) <= self.DEFER_WORKSPACE_LIMIT)
+            one_launch = bool(self.bank.step_info(plan, n, 0, 1)["fused"])
+            limit = min(self.DEFER_WORKSPACE_LIMIT, int(torch.cuda.mem_get_info(self.bank.device)[0] * self.DEFER_WORKSPACE_FRACTION))
+            self._defer_rule = (key, (not one_launch) and self.bank.deferred_workspace_bytes(plan, n) <= limit)
         return self._defer_rule[1]
 
     def attend(self, layer_idx: int, q, k, v):
@@ -410,8 +417,12 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                                              use_cache=True).logits[:, -1, :]
             finally:
                 _ACTIVE.reset(tk)
+            self.layout = cache.bank.layout_signature()     # the captured kernels are those of THIS score-row layout
 
         def __call__(self, tok, pos):
+            if self.cache.bank.layout_signature() != self.layout:
+                raise RuntimeError("the bank's score-row layout changed between capture and replay of the decode-step graph "
+                                   "(an eager call on the bank in between): capture again")
             self.tok.copy_(tok.view(1, 1))
             self.pos.fill_(pos)
             self.graph.replay()
@@ -485,6 +496,7 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                 all_logits.append(out.logits[0])
                 all_ids.append(input_ids[0, tok_i:tok_i + stride])
             cur_pos += stride
+        cache.bank.release_workspace(keep_bytes=64 << 20)      # (deferred chunk steps keep all layers' logits / column sums: not the decode phase's business)
         return logits_last, all_logits, all_ids
 
     result = None

@@ -465,6 +465,7 @@ static bool ekv_slot_rows_supported_impl(const ekv_bank* bank, const ekv_step* s
   const bool scored = st->policy == EKV_POLICY_H2O_HEAD || st->policy == EKV_POLICY_ROCO || st->policy == EKV_POLICY_TOVA;
   const int rep = bank->n_q_heads / bank->n_kv_heads;
   if (!bank->birth || !bank->slot_state || !scored || st->q_len != 1 || st->rope_on_read || st->n_evict > 1) return false;
+  if (!bank->score_sq || !bank->score_cnt) return false;      // (the tail keeps the count base of EVERY policy's appended row in score_cnt)
   if (st->score_off != 0 || st->win_lo != 0 || st->tova_head_mean || rep > 4 || !st->accumulate) return false;
   if (st->count_add != (float)(int)st->count_add) return false;      // counts stay exact integers (count = base + running sum)
   const int max_rows = 6144;      // (columns per thread in registers: 5 / 9 up to 2560 / 2304 rows, 12 / 24 beyond — 8-wave / 4-wave build)

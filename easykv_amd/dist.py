@@ -206,3 +206,21 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sum_over_ranks(value: float, device=None) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def all_gather_floats(value: float, device=None):
+    """One float of every rank, in rank order (a one-element all-gather over the job's backend)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

@@ -72,6 +72,7 @@ class KVBank:
         self._slot_min_tail = [1 << 30] * n_layers      # smallest protected tail of an evicting step since the conversion
         self._slot_ok = {}        # step shape -> does the slot-indexed decode kernel take it (ekv_step_check)
         self._slot_stretch = self._slot_short = 0      # steps since the layout was entered; short stretches seen (see _ensure_ordered)
+        self._slot_cool = 0       # one-launch decode steps run on the ordered layout since the thrash guard closed (see _enter_slot_rows)
         self.n_slots = [0] * n_layers
         # High-water mark of live rows per layer.  The library keeps the free list as [freed rows (most recent first), never-
         # used rows ascending] and appends take from its front, so every live row has a physical index < extent: the
@@ -97,6 +98,13 @@ class KVBank:
 
     # -- layout of the score rows -------------------------------------------------------------------
     use_slot_rows = True      # one-launch decode steps run on the slot-indexed layout where the library supports it
+    SLOT_COOL_DOWN = 256      # ordered one-launch decode steps after which a bank whose thrash guard closed tries the layout again
+
+    def layout_signature(self):
+        """Which layers hold the slot-indexed layout.  A hipGraph captured over steps of this bank replays the kernels of the layout
+        it was captured on: whoever replays one must find the same signature as at capture time (an eager call in between — a read
+        of ``bank.score_sum``, a chunk step — converts layers back; only the conversion itself is refused DURING a capture)."""
+        return tuple(self._slot_rows)
 
     def _ensure_ordered(self, layer_begin=0, layer_count=None):
         """Bring the score rows / slot map of the layers back to the ordered layout (every kernel but the one-launch decode step
@@ -125,8 +133,16 @@ class KVBank:
         """Decide whether this one-launch decode step runs on the slot-indexed layout, converting its layers if it does."""
         lb, lc = st.layer_begin, st.layer_count
         rows = self._slot_rows[lb:lb + lc]
-        if not (self.use_slot_rows and self._score_sum is not None) or len(set(self.n_slots[lb:lb + lc])) != 1 or self._slot_short >= 4:
+        if not (self.use_slot_rows and self._score_sum is not None) or len(set(self.n_slots[lb:lb + lc])) != 1:
             return False
+        if self._slot_short >= 4:
+            # thrash guard (see _ensure_ordered): the caller kept interleaving state reads with decode steps.  Not for ever — a
+            # generate that reads the state during its first tokens and then settles into pure decode gets the layout back after a
+            # cool-down of ordered steps; one more short stretch closes the guard again at once
+            self._slot_cool += 1
+            if self._slot_cool < self.SLOT_COOL_DOWN or torch.cuda.is_current_stream_capturing():
+                return False
+            self._slot_short, self._slot_cool = 3, 0
         st.phases = _lib.PHASE_SLOT_ROWS
         key = bytes(st)
         ok = self._slot_ok.get(key)
@@ -177,13 +193,20 @@ class KVBank:
             self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def release_workspace(self, keep_bytes=0):
+        """Drop the cached scratch buffer when it is larger than ``keep_bytes`` (a deferred chunk step of a long prefill keeps every
+        layer's logits / column sums alive until the flush: up to GBs that the decode phase after it never needs)."""
+        if self._ws is not None and self._ws.numel() > keep_bytes and (self._defer is None or not self._defer["pending"]):
+            self._ws = None
+            self._defer = None      # (its cached pointers referred to the buffer)
+
     def reset(self):
         check(self.lib.ekv_bank_reset(C.byref(self._bank), self._stream()), "ekv_bank_reset")
         self.n_slots = [0] * self.n_layers
         self.extent = [0] * self.n_layers
         self._slot_rows = [False] * self.n_layers
         self._slot_min_tail = [1 << 30] * self.n_layers
-        self._slot_stretch = self._slot_short = 0
+        self._slot_stretch = self._slot_short = self._slot_cool = 0
         self._defer = None      # (a half-open deferred token step dies with the bank's contents; arrive[] is zeroed by the reset)
 
     def abort_step(self):
@@ -436,11 +459,17 @@ class KVBank:
             self._ensure_ordered()      # (all layers in one launch: a layer-per-call caller would otherwise convert 32 times)
         st.phases = phases | (_lib.PHASE_SLOT_ROWS if slot else 0)
         if slot and st.n_evict > 0:
-            tail = st.roco_tail if st.policy == _lib.POLICY_ROCO else st.win_tail
-            if all(tail <= self._slot_min_tail[l] for l in range(layer_begin, layer_begin + lc)):
+            roco = st.policy == _lib.POLICY_ROCO
+            tail = st.roco_tail if roco else st.win_tail
+            # roco protects its newest entries by std = 1e9 sentinels only (easykv/easykv.py:318-321): when the feasible set has to
+            # reach into them (k1 > T - tail: budgets below ~30) the arg-min over the mean may evict one of the newest `tail`
+            # entries, and their births are no longer consecutive.  Such a step — and every step after it, until the next
+            # conversion — leaves the proof to the kernel's counting check (exact bisection when it fails).
+            breaks_tail = roco and st.roco_k1 > st.n_slots - st.roco_tail
+            if not breaks_tail and all(tail <= self._slot_min_tail[l] for l in range(layer_begin, layer_begin + lc)):
                 st.phases |= _lib.PHASE_SLOT_TAIL_OK
             for l in range(layer_begin, layer_begin + lc):
-                self._slot_min_tail[l] = min(self._slot_min_tail[l], tail)
+                self._slot_min_tail[l] = 0 if breaks_tail else min(self._slot_min_tail[l], tail)
         if out is None:
             out = torch.empty(lc, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
         want_ids = evict_ids is not False

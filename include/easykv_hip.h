@@ -186,7 +186,8 @@ int ekv_step_check(const ekv_bank *bank, const ekv_step *step);
  * run on it; ekv_rows_to_order converts back (slot map, score rows and zero tails exactly as the ordered steps would have left
  * them, counts included while all count_add were integers).  ekv_step_check / ekv_step_attend return EKV_E_UNSUPPORTED for a
  * flagged step the layout does not cover: anything but a one-launch decode step (q_len = 1, phases otherwise 0) with plain keys, a
- * scored policy with accumulate, score_off = 0, win_lo = 0, n_evict <= 1, GQA factor <= 4, phys_extent <= 6144, cap <= 9600. */
+ * scored policy with accumulate, score_off = 0, win_lo = 0, n_evict <= 1, GQA factor <= 4, phys_extent <= 6144, cap <= 9600, and a bank
+ * that carries score_sq and score_cnt (the count base of every policy's appended row lives in score_cnt). */
 #define EKV_PHASE_SLOT_ROWS 16
 /* with EKV_PHASE_SLOT_ROWS: the caller guarantees that this step's protected tail (roco: 10 entries; h2o_head: win_tail) is not
  * longer than that of any earlier evicting step since ekv_rows_to_slots — the newest entries then have consecutive births and the

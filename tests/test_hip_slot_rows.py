@@ -224,3 +224,65 @@ def test_a_caller_that_flips_the_layout_every_step_ends_up_on_the_ordered_one():
     assert used[:4] == [True] * 4 and used[-1] is False
     b.reset()
     assert b._slot_short == 0
+
+
+def test_roco_at_a_budget_whose_feasible_set_reaches_into_the_protected_tail():
+    """at budget 20 roco's feasible set (k1 = 14 of T = 21 entries) must reach into the 10 newest entries, which are
+    protected by std = 1e9 sentinels only (easykv/easykv.py:318-321) — the arg-min over the mean may then evict one of them, after
+    which the newest births are not consecutive and ``nb - tail`` is the wrong threshold.  The engine must not vouch for the tail
+    (EKV_PHASE_SLOT_TAIL_OK) on such a step or after it; the kernel's counting check + bisection then gives the ordered layout's
+    victims.  The sentinel entries tie exactly; both layouts break the tie to the older entry, so the ids must be EQUAL except at fp32
+    near-ties of the mean."""
+    from easykv_amd import StepPlan
+    L, Hq, H, D, budget = 2, 4, 4, 128, 20
+    (a, b), g = _banks(L, Hq, H, D, budget, seed=77)
+    plan = StepPlan(policy="roco", phase="decode", evict=True, score_off=0, budget=budget, n_split=1)
+    assert a.step_plan(plan, 1) == (1, True)
+    T = budget + 1
+    alive = torch.ones(L, H, dtype=torch.bool)
+    evicted_from_tail = 0
+    for i in range(300):
+        q, k, v = _mk(L, Hq, 1, D, g=g).cuda(), _mk(L, H, 1, D, g=g).cuda(), _mk(L, H, 1, D, g=g).cuda()
+        S0, C0 = a.score_sum.clone(), a.score_cnt.clone()
+        K0, _ = a.ordered_kv()
+        oa, ia = a.attend(plan, q, k, v)
+        ob, ib = b.attend(plan, q, k, v)
+        assert all(b._slot_rows)
+        evicted_from_tail += int((ia[:, :, 0] >= T - 10).sum())
+        same = (ia[:, :, 0] == ib[:, :, 0]).cpu()
+        for l, h in (~same & alive).nonzero().tolist():
+            keys = torch.cat([K0[l, h].float(), k[l, h].float()], 0)
+            p = torch.softmax((q[l, h:h + 1, 0].double() @ keys.double().T) / D ** 0.5, -1).mean(0)
+            mean = (S0[l, h, :T].double() + p) / (C0[l, h, :T].double() + 1.0)
+            va, vb = int(ia[l, h, 0]), int(ib[l, h, 0])
+            assert abs(float(mean[va] - mean[vb])) <= 1e-6 * abs(float(mean[va])), (i, l, h, va, vb)
+            alive[l, h] = False
+        m = alive.cuda()
+        assert torch.allclose(oa[m].float(), ob[m].float(), atol=1e-3, rtol=0), i
+    assert evicted_from_tail > 0, "no step evicted one of the 10 newest entries: the shape does not exercise the case"
+    assert float(alive.float().mean()) >= 0.75
+    mk = alive.cuda()
+    assert torch.equal(a.slot_of_pos[mk][:, :budget], b.slot_of_pos[mk][:, :budget])
+    assert torch.equal(a.score_cnt[mk], b.score_cnt[mk])
+
+
+def test_the_thrash_guard_reopens_after_a_cool_down():
+    """four short stretches early in a generate must not keep the bank on the ordered layout for the rest of the sequence."""
+    from easykv_amd import StepPlan
+    (a, b), g = _banks(2, 4, 4, 128, 120, seed=9)
+    b.SLOT_COOL_DOWN = 12
+    plan = StepPlan(policy="roco", phase="decode", evict=True, score_off=0, budget=120, n_split=1)
+
+    def step():
+        q, k, v = _mk(2, 4, 1, 128, g=g).cuda(), _mk(2, 4, 1, 128, g=g).cuda(), _mk(2, 4, 1, 128, g=g).cuda()
+        assert torch.equal(a.attend(plan, q, k, v)[1], b.attend(plan, q, k, v)[1])
+    for i in range(6):                       # a caller that reads the state after every step: the guard closes
+        step()
+        _ = b.score_cnt
+    assert b._slot_short >= 4
+    used = []
+    for i in range(40):                      # ... then settles into pure decode
+        step()
+        used.append(all(b._slot_rows))
+    assert not any(used[:10]) and all(used[-20:])
+    assert torch.equal(a.score_cnt, b.score_cnt) and torch.equal(a.slot_of_pos[:, :, :120], b.slot_of_pos[:, :, :120])

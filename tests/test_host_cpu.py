@@ -216,3 +216,20 @@ def test_step_check_is_a_dry_run_of_step_attend():
     b, s = _fake_bank_step(**slot)
     b.birth = None
     assert ok(b, s) == -2                                                      # a bank without the slot-layout arrays
+
+
+def test_bench_refuses_to_label_fewer_ranks_as_n_gpus():
+    """``python bench.py --gpus N`` without a launcher starts N ranks itself; on a box with fewer GPUs than N it must
+    refuse, not run one rank and print ``n_gpus: 1`` (this container has no GPU at all)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
