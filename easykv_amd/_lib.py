@@ -74,7 +74,7 @@ def load():
     lib.ekv_rows_to_order.argtypes = [C.POINTER(Bank), i32, i32, i32, vp]
     for name in EXPORTS[3:]:
         getattr(lib, name).restype = C.c_int
-    if lib.ekv_abi_version() != 6:
+    if lib.ekv_abi_version() != 7:
         raise EkvError("ABI version mismatch")
     _lib = lib
     return lib

@@ -108,6 +108,7 @@ class BudgetedKVCache:
         self._cur = None
         self.score_prefix = False
         self.n_attend = 0        # attend() calls of the forward in flight (checked by the driver after every forward)
+        self._defer_this_forward = None
         self.defer_chunk_scorer = True     # scored chunk steps of a layer-per-call model: one scorer launch per forward (round 4)
 
     def owns(self, layer_idx: int) -> bool:
@@ -125,6 +126,7 @@ class BudgetedKVCache:
         self.plan = plan
         self.positions = positions
         self.n_attend = 0
+        self._defer_this_forward = None      # decided by the forward's first attend() (all owned layers still hold the same length)
         self._cur = [] if (self.record and plan.evict) else None
         if self._cur is not None:
             self.evictions.append(self._cur)
@@ -188,8 +190,10 @@ class BudgetedKVCache:
                                         v[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), layer_begin=layer_idx)
                 outs.append(o)
             return torch.cat(outs, dim=2)
-        deferable_chunk = (n > 1 and plan.phase == "prefill" and plan.policy in ("roco", "h2o_head", "tova") and (plan.accumulate or plan.evict)
-                           and self.defer_chunk_scorer and self._defer_fits(plan, n))
+        if self._defer_this_forward is None:      # one decision per forward: an immediate step advances its layer's length at once
+            self._defer_this_forward = bool(n > 1 and plan.phase == "prefill" and plan.policy in ("roco", "h2o_head", "tova") and (plan.accumulate or plan.evict)
+                                            and self.defer_chunk_scorer and self._defer_fits(plan, n))
+        deferable_chunk = self._defer_this_forward
         if ((n == 1 and plan.phase == "decode") or deferable_chunk) and self.layer_count > 1:
             # one layer per call (a decoder stack): attention + fold of this layer now, the scorers of all owned layers in ONE
             # launch after the last layer (KVBank.flush) — off the critical path of the stack.  Decode steps, and since round 4 the

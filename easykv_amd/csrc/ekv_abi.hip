@@ -398,8 +398,12 @@ size_t ekv_workspace_bytes(const ekv_bank* bank, const ekv_step* step) {
   return ekv_plan_workspace(bank, &full, nullptr).bytes;
 }
 
+// what a dry run reports about the dispatch: one_launch = the whole step is ONE launch; n_launches = kernel launches of the call
+struct EkvPlanOut {
+  int32_t one_launch, n_launches;
+};
 static int step_attend_impl(const ekv_bank*, const ekv_step*, const void*, const void*, const void*, void*, int32_t*, const float*,
-                            const float*, void*, size_t, void*, bool, int32_t*);
+                            const float*, void*, size_t, void*, bool, EkvPlanOut*);
 
 int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, int32_t* fused) {
   if (int e = check_bank(bank)) return e;
@@ -408,9 +412,9 @@ int ekv_step_plan(const ekv_bank* bank, const ekv_step* st, int32_t* n_split, in
   *n_split = ws.n_split;
   // one launch for the whole step: the fused decode kernel, the logits-in-LDS chunk kernel, or a chunk step whose scorer runs
   // as the tail of the attention kernel — asked of the dispatch itself (dry run); a step the dispatch would refuse plans as 0
-  int32_t one = 0;
-  if (step_attend_impl(bank, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true, &one) != EKV_OK) one = 0;
-  *fused = (one && (st->phases & ~(EKV_PHASE_SLOT_ROWS | EKV_PHASE_SLOT_TAIL_OK)) == 0) ? 1 : 0;
+  EkvPlanOut po{};
+  if (step_attend_impl(bank, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true, &po) != EKV_OK) po.one_launch = 0;
+  *fused = (po.one_launch && (st->phases & ~(EKV_PHASE_SLOT_ROWS | EKV_PHASE_SLOT_TAIL_OK)) == 0) ? 1 : 0;
   return EKV_OK;
 }
 
@@ -420,7 +424,9 @@ int ekv_step_info(const ekv_bank* bank, const ekv_step* st, int32_t* info, int32
   int32_t n_split = 0, fused = 0;
   if (int e = ekv_step_plan(bank, st, &n_split, &fused)) return e;
   const EkvWs ws = ekv_plan_workspace(bank, st, nullptr);
-  const int32_t v[EKV_STEP_INFO_N] = {n_split, fused, ws.two_pass, ws.wide, ws.n_qblocks, ws.qb_rows, ws.n_col_parts, ws.fold_in_kernel};
+  EkvPlanOut po{};
+  if (step_attend_impl(bank, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true, &po) != EKV_OK) po.n_launches = 0;
+  const int32_t v[EKV_STEP_INFO_N] = {n_split, fused, ws.two_pass, ws.wide, ws.n_qblocks, ws.qb_rows, ws.n_col_parts, ws.fold_in_kernel, po.n_launches};
   for (int i = 0; i < n_info && i < EKV_STEP_INFO_N; ++i) info[i] = v[i];
   for (int i = EKV_STEP_INFO_N; i < n_info; ++i) info[i] = 0;
   return EKV_OK;
@@ -478,8 +484,10 @@ static bool ekv_slot_rows_supported_impl(const ekv_bank* bank, const ekv_step* s
 // needed.
 static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void* q, const void* k_new, const void* v_new,
                             void* out, int32_t* evict_ids, const float* rope_cos, const float* rope_sin, void* workspace,
-                            size_t workspace_bytes, void* stream, bool dry, int32_t* one_launch) {
-  if (one_launch) *one_launch = 0;
+                            size_t workspace_bytes, void* stream, bool dry, EkvPlanOut* plan_out) {
+  int32_t one_launch_dummy = 0;
+  int32_t* const one_launch = plan_out ? &plan_out->one_launch : &one_launch_dummy;
+  if (plan_out) plan_out->one_launch = plan_out->n_launches = 0;
   if (int e = check_bank(bank)) return e;
   if (!st) return EKV_E_ARG;
   // EKV_PHASE_SLOT_ROWS: the bank's score rows are in the slot-indexed layout (ekv_rows_to_slots) — only the one-launch decode step
@@ -620,7 +628,8 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
       sa.cnt_tail = ekv_cnt_tail(bank);
       sa.slot_tail_ok = slot_tail_ok ? 1 : 0;
     }
-    if (one_launch) *one_launch = 1;
+    *one_launch = 1;
+    if (plan_out) plan_out->n_launches = 1;
     if (dry) return EKV_OK;
     return ekv_launch_decode_fused(aa, sa, bank->head_dim, st->layer_count, ws.fused_nw, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
@@ -629,7 +638,8 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // small-row chunk step (configs[1]: stride 8): one launch, logits in LDS, K and V read once
   if (n > 1 && ekv_chunk_lds_supported(bank, st, aa.phys_extent, scored) &&
       (st->layer_count * bank->n_kv_heads >= 256 || T <= 1024)) {
-    if (one_launch) *one_launch = 1;
+    *one_launch = 1;
+    if (plan_out) plan_out->n_launches = 1;
     if (dry) return EKV_OK;
     return ekv_launch_chunk_lds(aa, sa, bank->head_dim, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
   }
@@ -648,7 +658,15 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
                           rep * n <= 64 && !(st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) &&
                           ekv_score_lds_bytes_nt256(sa) <= 64 * 1024 && st->n_split != -1;
   if (fuse_chunk) sa.skip_fold = 1;
-  if (fuse_chunk && one_launch) *one_launch = 1;
+  if (fuse_chunk) *one_launch = 1;
+  // Two-pass step on the wide-block kernel (whole step, or the flush of a layer-per-call step whose column-sum pass was deferred):
+  // the scorer runs as the TAIL of the column-sum pass (ekv_wide_tail.h, round 5) — score rows in registers, keys in the pass's
+  // tile buffers, four workgroups per CU — instead of a 1024-thread-per-CU scorer launch behind it.  A head whose column sums come
+  // from several workgroups (key-range splits / query-block groups) is scored by the last of them to arrive (bank->arrive).
+  const bool flush_colsum = (ph & 8) && !(ph & 1) && n > 1 && ws.q_keep != nullptr;
+  const int tail_wgs = ws.n_split * ws.n_col_parts;
+  const bool tail_step = n > 1 && ws.wide && ws.two_pass && (ph == 0 || flush_colsum) && ws.big_rows == nullptr && scored && st->accumulate &&
+                         st->policy != EKV_POLICY_TOVA && ekv_wide_tail_supported(W, tail_wgs, bank->arrive != nullptr);
 
   // How the step ends, decided BEFORE anything is launched: a shape no scorer can take must be refused while the bank is
   // still untouched (the attention kernel appends the new rows).
@@ -661,12 +679,32 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   if (wants_scorer && !fold_only && !range_only && !fuse_chunk && !fast_scorer && ekv_score_lds_bytes(sa) > 160 * 1024)
     return EKV_E_UNSUPPORTED;   // even the selection keys alone exceed one CU's LDS (W > ~39 000): see DESIGN.md "size limits"
   if (n == 1 ? !ekv_attn_decode_supported(bank->head_dim, rep) : !ekv_attn_chunk_supported(bank->head_dim, rep, n)) return EKV_E_UNSUPPORTED;
-  if (dry) return EKV_OK;
 
   // decode split path whose partials are folded right behind the attention kernel (attention + fold phases, or a step that has
   // nothing to score): the last-arriving split of a head folds them inside the attention kernel — no fold launch
   const bool fold_in_decode = n == 1 && bank->arrive != nullptr && (ph == 0 || (ph & 1)) && !ws.fold_in_kernel &&
                               ((ph & 4) || (ph == 0 && (fold_only || range_only)));
+  if (plan_out) {      // kernel launches of this call (ekv_step_info): the same tests as the launch sequence below, in its order
+    int nl = 0;
+    if (ph == 0 || (ph & 1))
+      nl += n == 1 ? 1 : ((st->rope_on_read && !ws.wide ? 1 : 0) + (ws.two_pass ? (ws.q_keep != nullptr ? 1 : 2) : 1));
+    if (!(ph == 1 || fuse_chunk)) {
+      if (tail_step && ph == 0) {
+        nl += ws.fold_in_kernel ? 0 : 1;
+      } else {
+        if (((ph & 4) || fold_only || range_only) && (!(ph & 8) || (ph & 4)) && !ws.fold_in_kernel && !fold_in_decode) ++nl;
+        if (!fold_only) {
+          if (range_only) nl += st->n_evict > 0 ? 1 : 0;
+          else {
+            if (flush_colsum) ++nl;
+            if (!tail_step) nl += 1 + ((!fast_scorer && st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) ? 1 : 0);
+          }
+        }
+      }
+    }
+    plan_out->n_launches = nl;
+  }
+  if (dry) return EKV_OK;
   if (fold_in_decode) {
     aa.arrive = bank->arrive + (size_t)st->layer_begin * bank->n_kv_heads;
     aa.out_direct = static_cast<__half*>(out);
@@ -675,6 +713,15 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   } else if (n == 1) {
     err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
   } else {
+    if (tail_step && ph == 0) {
+      // one pass (output / partials + row statistics) -> fold of the key-range partials, if any -> column-sum pass with the scorer as
+      // its tail: two launches for an unsplit head
+      if (tail_wgs > 1) aa.arrive = bank->arrive + (size_t)st->layer_begin * bank->n_kv_heads;
+      sa.skip_fold = 1;
+      if (ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, true, s, nullptr, 1) != hipSuccess) return EKV_E_LAUNCH;
+      if (!ws.fold_in_kernel && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+      return ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, true, s, nullptr, 2, &sa) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+    }
     // (deferred wide two-pass step: only the one pass now — the column-sum pass runs with the scorer at the flush)
     err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, ws.two_pass != 0, s, fuse_chunk ? &sa : nullptr, ws.q_keep != nullptr ? 1 : 3);
   }
@@ -696,14 +743,16 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
     }
     return EKV_OK;
   }
-  if ((ph & 8) && !(ph & 1) && n > 1 && ws.q_keep != nullptr) {
+  if (flush_colsum) {
     // the flush of a deferred chunk step: the column-sum pass of ALL layers (queries from the kept copies, the chunk's own rows from
-    // the cache slots the one pass of each layer wrote them to), then the scorer
+    // the cache slots the one pass of each layer wrote them to), then the scorer — as the tail of that pass where it can be
     EkvAttnArgs a2 = aa;
     a2.q = ws.q_keep;
     a2.q_keep = nullptr;
     a2.new_in_cache = 1;
-    if (ekv_launch_attn_chunk(a2, bank->head_dim, st->layer_count, true, s, nullptr, 2) != hipSuccess) return EKV_E_LAUNCH;
+    if (tail_step && tail_wgs > 1) a2.arrive = bank->arrive + (size_t)st->layer_begin * bank->n_kv_heads;
+    if (ekv_launch_attn_chunk(a2, bank->head_dim, st->layer_count, true, s, nullptr, 2, tail_step ? &sa : nullptr) != hipSuccess) return EKV_E_LAUNCH;
+    if (tail_step) return EKV_OK;
   }
   sa.skip_fold = ((ph & 8) || ws.fold_in_kernel) ? 1 : 0;
   if (fast_scorer)   // decode steps: the fast scorer (same tail as the fused kernel)

@@ -9,10 +9,10 @@ EKV_DECL(32, 0) EKV_DECL(32, 1) EKV_DECL(32, 2) EKV_DECL(64, 0) EKV_DECL(64, 1) 
 EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 #undef EKV_DECL
 
-#define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t);
+#define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t, const EkvScoreArgs*);
 EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
 #undef EKW_DECL
-#define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_rope_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t);
+#define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_rope_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t, const EkvScoreArgs*);
 EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
 #undef EKW_DECL
 
@@ -101,9 +101,18 @@ static int kernel_code(int qpw, bool rope, int mode) { return (qpw == 4 && !rope
 int ekv_chunk_col_parts(int qpw, bool rope) { (void)rope; return qpw == 4 ? 4 : 2; }
 
 // fuse_sc != nullptr: one-pass step with unsplit heads whose scorer runs as the tail of the attention kernel (no second launch)
+// The scorer as the tail of the wide column-sum pass holds the score rows of a head in registers (24 columns per thread of a
+// 256-thread workgroup) and the selection keys in the pass's tile buffers; heads written by several workgroups need the bank's
+// arrival counters
+bool ekv_wide_tail_supported(int W, int n_wg, bool have_arrive) {
+  static const bool off = [] { const char* e = std::getenv("EKV_NO_WIDE_TAIL"); return e != nullptr && e[0] == '1'; }();     // (A/B switch)
+  return !off && W >= 1 && W <= 24 * 256 && (n_wg == 1 || (have_arrive && n_wg <= 256));
+}
+
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
-                                 const EkvScoreArgs* fuse_sc, int passes) {
+                                 const EkvScoreArgs* fuse_sc, int passes, const EkvScoreArgs* tail_sc) {
   if (two_pass && fuse_sc != nullptr) return hipErrorInvalidValue;
+  if (tail_sc != nullptr && !(two_pass && (passes & 2))) return hipErrorInvalidValue;
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
   if (qb_rows != a.qb_rows || n_qblocks != a.n_qblocks) return hipErrorInvalidValue;
@@ -120,13 +129,18 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
     const int nwq = qpw == 4 ? 4 : 2;
     // one pass over K and V (output, and for a scored step every row's softmax statistics), then — scored steps — the column-sum
     // pass over K
-#define EKW_GO(d, m) (rope ? ekv_launch_attn_wide_rope_d##d##_m##m(a, nwq, layer_count, s) : ekv_launch_attn_wide_d##d##_m##m(a, nwq, layer_count, s))
+#define EKW_GO(d, m, aa, t) (rope ? ekv_launch_attn_wide_rope_d##d##_m##m(aa, nwq, layer_count, s, t) : ekv_launch_attn_wide_d##d##_m##m(aa, nwq, layer_count, s, t))
     hipError_t e = hipSuccess;
-    if (passes & 1) e = head_dim == 128 ? EKW_GO(128, 0) : EKW_GO(64, 0);
-    if (two_pass && (passes & 2) && e == hipSuccess) e = head_dim == 128 ? EKW_GO(128, 2) : EKW_GO(64, 2);
+    if (passes & 1) e = head_dim == 128 ? EKW_GO(128, 0, a, nullptr) : EKW_GO(64, 0, a, nullptr);
+    if (two_pass && (passes & 2) && e == hipSuccess) {
+      EkvAttnArgs a2 = a;
+      a2.score_tail = tail_sc != nullptr ? 1 : 0;
+      e = head_dim == 128 ? EKW_GO(128, 2, a2, tail_sc) : EKW_GO(64, 2, a2, tail_sc);
+    }
 #undef EKW_GO
     return e;
   }
+  if (tail_sc != nullptr) return hipErrorInvalidValue;
   if (two_pass && (a.stats == nullptr || a.colsum == nullptr || a.n_col_parts != ekv_chunk_col_parts(qpw, rope) * n_qblocks)) return hipErrorInvalidValue;
 #define EKV_GO(d, m) ekv_launch_attn_chunk_d##d##_m##m(a, kernel_code(qpw, rope, m), layer_count, s, fuse_sc)
   hipError_t e = hipSuccess;

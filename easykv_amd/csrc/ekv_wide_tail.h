@@ -1,0 +1,194 @@
+// Scorer of a two-pass wide chunk step as the TAIL of the column-sum pass (ekv_attn_wide.inc, EKV_WIDE_MODE 2; round 5).
+//
+// Replaces, for those steps, the stand-alone ekv_score_select_kernel launch (same reference sites: accumulate
+// easykv/easykv.py:443-457, count advance :460, select :462-490, score-row + K/V compaction :465-490 / :56-82 as a slot-map compaction).
+// That launch was latency-bound and on the critical path of every wide step: W = 5098 columns are 87 KB of LDS with S / Q / C and the
+// keys resident, i.e. ONE 1024-thread workgroup per CU and four dispatch rounds of ~27 us (112 us of a 0.93 ms configs[3] step, 20 %
+// of a configs[2] step).  Here the workgroup that finishes a head's column sums scores and evicts the head itself:
+//   * the score rows live in REGISTERS (thread-owned columns j = tid + 256 * it; S, Q, C: 3 x ITEMS), only the selection keys in LDS
+//     (4 B per column, in the tile buffers the stream has left): the pass keeps its four workgroups per CU, all 1024 heads of a
+//     32-layer launch are scored side by side instead of in four rounds, and the launch boundary in front of the scorer is gone;
+//   * the arithmetic, the order of the sums and the exact selects (blk_mark_k_smallest: range histogram, refinement, radix / tie
+//     fallbacks) are those of ekv_score_select_body, so the decisions are the stand-alone scorer's bit for bit.
+// A head whose column sums come from SEVERAL workgroups (key-range splits, query-block groups: launches of few heads) is scored by the
+// last of them to arrive (ekv_bank.arrive, the protocol of the split decode kernel): see ekw_tail_arrive below.
+#pragma once
+
+// Included after ekv_score_select.inc (EKV_SS_NT 256, EKV_SS_DEVICE_ONLY): Blk, blk_mark_k_smallest, kNT, kNWV.
+
+constexpr int kTailItems = 24;                       // owned columns per thread: score rows of up to 24 * 256 = 6144 positions
+
+__host__ __device__ inline size_t ekw_tail_lds_bytes(int W) {      // keys | reduction scratch | histogram | candidate list
+  return ekv_align((size_t)W * 4, 16) + 2 * 4 * 8 * 4 + 264 * 4 + 256 * 8;
+}
+
+// Last-arriver election for heads whose column sums are written by `n_wg` workgroups of this launch: every workgroup's sums are
+// complete in memory (agent-scope release by one lane behind a workgroup barrier), ONE atomic per workgroup on the head's counter;
+// the workgroup that observes n_wg - 1 resets the counter for the next launch, acquires, and runs the tail.  -> true in every
+// thread of the elected workgroup.
+__device__ __forceinline__ bool ekw_tail_arrive(uint32_t* counter, const int n_wg, uint32_t* s_flag) {
+  __syncthreads();                                   // every thread's column-sum stores are issued and (vmcnt(0)) complete
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (MI355X_MICROARCH.md: hipcc may drop the wait behind the write-back)
+    const uint32_t seen = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = seen == (uint32_t)(n_wg - 1);
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *s_flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return *s_flag != 0u;
+}
+
+template <int ITEMS>
+__device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int h, const int ll, char* smem) {
+  static_assert(kNT == 256, "the tail runs on the 256-thread workgroups of the wide-block kernel");
+  const int tid = threadIdx.x;
+  const int T = a.n_slots, off = a.score_off, W = T - off, k = a.n_evict;
+  const bool roco = a.policy == EKV_POLICY_ROCO;
+  const size_t head_row = ((size_t)(a.layer_begin + ll) * a.n_kv_heads + h) * a.cap;
+  const float* const cp0 = a.colsum + ((size_t)ll * a.n_kv_heads + h) * a.n_col_parts * 2 * a.t_pad + off;
+  uint32_t* const sKey = reinterpret_cast<uint32_t*>(smem);
+  Blk b;
+  b.tid = tid;
+  b.lane = tid & 63;
+  b.wave = tid >> 6;
+  b.red = reinterpret_cast<unsigned long long*>(smem + ekv_align((size_t)W * 4, 16));
+  b.phase = 0;
+  uint32_t* const sHist = reinterpret_cast<uint32_t*>(b.red) + 2 * kNWV * 8;      // 264 words, then the select's candidate list (kNT uint64)
+
+  // ---- 1. score rows + this forward's column sums (parts in order 0, 1, ...: ekv_score_select_body's summation order) ----------
+  float rS[ITEMS], rQ[ITEMS], rC[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    rS[it] = rQ[it] = rC[it] = 0.f;
+    if (it * kNT < W) {                              // (workgroup-uniform)
+      const int j = min(tid + it * kNT, W - 1);      // unconditional (clamped) loads
+      const float s = a.score_sum[head_row + j];
+      float q = 0.f, c = 0.f;
+      if (roco) {
+        q = a.score_sq[head_row + j];
+        c = a.score_cnt[head_row + j];
+      }
+      float cs = 0.f, cq = 0.f;
+      for (int part = 0; part < a.n_col_parts; ++part) {
+        cs += cp0[(size_t)(2 * part) * a.t_pad + j];
+        cq += cp0[(size_t)(2 * part + 1) * a.t_pad + j];
+      }
+      rS[it] = s + cs;
+      rQ[it] = q + cq;
+      rC[it] = c;
+    }
+  }
+  if (k <= 0) {                                      // an accumulating step that evicts nothing (the scored dense prefix)
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * kNT;
+      if (j < W) {
+        a.score_sum[head_row + j] = rS[it];
+        if (roco) a.score_sq[head_row + j] = rQ[it];
+      }
+    }
+    return;
+  }
+
+  // ---- 2. selection: flags in sKey (1 = evict) -------------------------------------------------------------------------------
+  if (roco) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * kNT;
+      if (j < W) {
+        const float c = rC[it] + a.count_add;
+        rC[it] = c;
+        const float mean = rS[it] / c;
+        float sd = sqrtf(rQ[it] / c - mean * mean);
+        if (j >= W - a.roco_tail || j < a.win_lo) sd = 1e9f;
+        sKey[j] = ekv_fkey(sd);
+      }
+    }
+    __syncthreads();
+    [[clang::always_inline]] blk_mark_k_smallest(b, sKey, W, a.roco_k1, sHist, ekv_fkey(1e9f));      // feasible set
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * kNT;
+      if (j < W) sKey[j] = sKey[j] ? ekv_fkey(rS[it] / rC[it]) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    [[clang::always_inline]] blk_mark_k_smallest(b, sKey, W, k, sHist);
+  } else {                                           // h2o_head: k smallest accumulated scores inside the candidate window
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int j = tid + it * kNT;
+      if (j < W) sKey[j] = (j >= a.win_lo && j < W - a.win_tail) ? ekv_fkey(rS[it]) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    [[clang::always_inline]] blk_mark_k_smallest(b, sKey, W, k, sHist);
+  }
+
+  // slot-map cells of the owned columns: requested now, consumed behind the scan's barriers
+  int32_t cell[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    cell[it] = 0;
+    if (it * kNT < W) cell[it] = a.slot_of_pos[head_row + off + min(tid + it * kNT, W - 1)];
+  }
+
+  // ---- 3. destinations: kept j -> #kept before j ; evicted j -> -(1 + #evicted before j)  (ekv_score_select_body step 4b) --------
+  {
+    const int items = (W + kNT - 1) / kNT;
+    const int c0 = min(W, tid * items), c1 = min(W, c0 + items);
+    int kept = 0;
+    for (int j = c0; j < c1; ++j) kept += sKey[j] ? 0 : 1;
+    int incl = kept;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(incl, o, 64);
+      if (b.lane >= o) incl += y;
+    }
+    int* r = reinterpret_cast<int*>(b.red) + (b.phase & 1) * kNWV * 2;
+    if (b.lane == 63) r[b.wave] = incl;
+    __syncthreads();
+    int base = incl - kept;
+    for (int i = 0; i < b.wave; ++i) base += r[i];
+    b.phase++;
+    for (int j = c0; j < c1; ++j) {
+      if (sKey[j]) {
+        sKey[j] = (uint32_t)(-(1 + (j - base)));
+      } else {
+        sKey[j] = (uint32_t)base;
+        base++;
+      }
+    }
+    __syncthreads();       // (also: every thread's cell loads have completed before any thread stores to the slot map)
+  }
+
+  // ---- 4. write back from the registers: compacted score rows, evict ids (ascending), compacted slot map -----------------------
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int j = tid + it * kNT;
+    if (j < W) {
+      const int d = (int)sKey[j];
+      if (d >= 0) {
+        a.score_sum[head_row + d] = rS[it];
+        if (roco) {
+          a.score_sq[head_row + d] = rQ[it];
+          a.score_cnt[head_row + d] = rC[it];
+        }
+        a.slot_of_pos[head_row + off + d] = cell[it];
+      } else {
+        const int e = -1 - d;
+        if (a.evict_ids != nullptr) a.evict_ids[((size_t)ll * a.n_kv_heads + h) * k + e] = off + j;
+        a.slot_of_pos[head_row + off + (W - k) + e] = cell[it];      // the victims' rows become the free tail
+      }
+    }
+  }
+  for (int i = tid; i < k; i += kNT) {
+    a.score_sum[head_row + W - k + i] = 0.f;
+    if (roco) {
+      a.score_sq[head_row + W - k + i] = 0.f;
+      a.score_cnt[head_row + W - k + i] = (float)i * a.count_tail_step;
+    }
+  }
+}

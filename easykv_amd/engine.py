@@ -315,9 +315,9 @@ class KVBank:
         """The library's dispatch decisions for this step (ekv_step_info): n_split, fused, two_pass, wide, n_qblocks, ..."""
         st = self.make_step(plan, q_len, layer_begin, self.n_layers - layer_begin if layer_count is None else layer_count)
         st.phases = phases
-        info = (C.c_int32 * 8)()
-        check(self.lib.ekv_step_info(C.byref(self._bank), C.byref(st), info, 8), "ekv_step_info")
-        keys = ("n_split", "fused", "two_pass", "wide", "n_qblocks", "qb_rows", "n_col_parts", "fold_in_kernel")
+        info = (C.c_int32 * 9)()
+        check(self.lib.ekv_step_info(C.byref(self._bank), C.byref(st), info, 9), "ekv_step_info")
+        keys = ("n_split", "fused", "two_pass", "wide", "n_qblocks", "qb_rows", "n_col_parts", "fold_in_kernel", "n_launches")
         return dict(zip(keys, (int(x) for x in info)))
 
     def join(self):

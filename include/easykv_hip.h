@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define EKV_ABI_VERSION 6
+#define EKV_ABI_VERSION 7
 
 /* kv_policy strings of the reference -> codes (easykv/easykv.py:288-300, :310-362) */
 enum {
@@ -135,10 +135,11 @@ int ekv_step_plan(const ekv_bank *bank, const ekv_step *step, int32_t *n_split, 
 /* The dispatch decisions behind ekv_step_plan, for host code that must shape its calls after them instead of mirroring the rules
  * (ABI 5): info[0 .. n_info) <- { n_split, fused, two_pass (1 = statistics + column-sum scheme, no logits in HBM), wide (1 = the
  * 32x32x16 wide-block kernel, which walks all query blocks of a head inside one launch), n_qblocks, qb_rows, n_col_parts,
- * fold_in_kernel }; entries beyond EKV_STEP_INFO_N are zeroed.  The reference has no counterpart (its keep_attention prefix
+ * fold_in_kernel, n_launches (ABI 7: kernel launches this call issues — a two-pass wide step is 2 since the scorer became the tail
+ * of its column-sum pass, 3 before; 0 = the dispatch refuses the step) }; entries beyond EKV_STEP_INFO_N are zeroed.  The reference has no counterpart (its keep_attention prefix
  * materialises the r x r map, easykv/easykv.py:396-405); easykv_amd.api uses it to decide whether a scored prefix goes down as
  * one step or in query blocks. */
-#define EKV_STEP_INFO_N 8
+#define EKV_STEP_INFO_N 9
 int ekv_step_info(const ekv_bank *bank, const ekv_step *step, int32_t *info, int32_t n_info);
 
 /* slot_of_pos <- identity for the whole bank */

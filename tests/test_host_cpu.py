@@ -40,7 +40,7 @@ def test_abi_exports_every_declared_symbol():
     raw = ctypes.CDLL(_build.LIB)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.ekv_abi_version() == 6
+    assert lib.ekv_abi_version() == 7
     assert lib.ekv_rows_to_slots(None, 0, 1, 1, None) == -1 and lib.ekv_rows_to_order(None, 0, 1, 1, None) == -1
     assert lib.ekv_step_info(None, None, None, 0) == -1
     assert b"workspace" in lib.ekv_strerror(-3)
