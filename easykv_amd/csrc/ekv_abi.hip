@@ -663,10 +663,11 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // the scorer runs as the TAIL of the column-sum pass (ekv_wide_tail.h, round 5) — score rows in registers, keys in the pass's
   // tile buffers, four workgroups per CU — instead of a 1024-thread-per-CU scorer launch behind it.  A head whose column sums come
   // from several workgroups (key-range splits / query-block groups) is scored by the last of them to arrive (bank->arrive).
+  // Not with RoPE-on-read: those passes run two workgroups per CU, where a head's ~50 us tail costs more stream than the launch it saves.
   const bool flush_colsum = (ph & 8) && !(ph & 1) && n > 1 && ws.q_keep != nullptr;
   const int tail_wgs = ws.n_split * ws.n_col_parts;
   const bool tail_step = n > 1 && ws.wide && ws.two_pass && (ph == 0 || flush_colsum) && ws.big_rows == nullptr && scored && st->accumulate &&
-                         st->policy != EKV_POLICY_TOVA && ekv_wide_tail_supported(W, tail_wgs, bank->arrive != nullptr);
+                         st->policy != EKV_POLICY_TOVA && !st->rope_on_read && ekv_wide_tail_supported(W, tail_wgs, bank->arrive != nullptr);
 
   // How the step ends, decided BEFORE anything is launched: a shape no scorer can take must be refused while the bank is
   // still untouched (the attention kernel appends the new rows).

@@ -10,6 +10,16 @@
 //     32-layer launch are scored side by side instead of in four rounds, and the launch boundary in front of the scorer is gone;
 //   * the arithmetic, the order of the sums and the exact selects (blk_mark_k_smallest: range histogram, refinement, radix / tie
 //     fallbacks) are those of ekv_score_select_body, so the decisions are the stand-alone scorer's bit for bit.
+// Measured (MI355X, cycle stamps per head at the configs[3] shape, -DEKV_TAIL_PROFILE; all 1024 heads in their tails at once): loads +
+// accumulate 28.4 k cycles (105 MB of score rows and column sums: bandwidth), keys 9.1 k, select k1 18.6 k, mean keys + select k 23.1 k,
+// scan 7.4 k, write-back 19.2 k = 105.6 k cycles ~ 50 us per head against 4 x 27 us of the stand-alone launch: configs[3] step 879 vs 937
+// us same box, stride 64 387 vs 402, configs[2] 91.4 vs 92.8.  NOT for the RoPE-on-read builds: at their two workgroups per CU a 50 us
+// tail leaves the CU's other workgroup streaming alone (configs[4] step 2434 vs 2385 us) — those keep the stand-alone scorer.
+// Built and rejected: the selection keys in registers too (warm-started window -> range histogram with refinement -> bisection, the
+// scheme of the slot-indexed decode tail; destinations by ballots + mbcnt instead of a scan over LDS): bit-identical, but 160 live
+// registers against the pass's 128-register bound (four workgroups per CU) — 51-85 spilled registers, every phase of the tail 1.5-3x
+// slower (177 k cycles per head) — and in the RoPE builds, which have the registers, the tail took the same 147 us as this version:
+// the chain of ~40 workgroup barriers and its memory round trips, not the LDS sweeps of the selects, is what a head's tail costs.
 // A head whose column sums come from SEVERAL workgroups (key-range splits, query-block groups: launches of few heads) is scored by the
 // last of them to arrive (ekv_bank.arrive, the protocol of the split decode kernel): see ekw_tail_arrive below.
 #pragma once
@@ -59,6 +69,13 @@ __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int 
   b.red = reinterpret_cast<unsigned long long*>(smem + ekv_align((size_t)W * 4, 16));
   b.phase = 0;
   uint32_t* const sHist = reinterpret_cast<uint32_t*>(b.red) + 2 * kNWV * 8;      // 264 words, then the select's candidate list (kNT uint64)
+#ifdef EKV_TAIL_PROFILE      // cycle stamps per head in the (unused) tova_row scratch: tools/experiments/exp_widetail_prof.py
+  unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(a.tova_row) + ((size_t)ll * a.n_kv_heads + h) * 8;
+#define EKW_TSTAMP(i) do { __syncthreads(); if (threadIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EKW_TSTAMP(i) do { } while (0)
+#endif
+  EKW_TSTAMP(0);
 
   // ---- 1. score rows + this forward's column sums (parts in order 0, 1, ...: ekv_score_select_body's summation order) ----------
   float rS[ITEMS], rQ[ITEMS], rC[ITEMS];
@@ -83,6 +100,7 @@ __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int 
       rC[it] = c;
     }
   }
+  EKW_TSTAMP(1);
   if (k <= 0) {                                      // an accumulating step that evicts nothing (the scored dense prefix)
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -110,7 +128,9 @@ __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int 
       }
     }
     __syncthreads();
+    EKW_TSTAMP(2);
     [[clang::always_inline]] blk_mark_k_smallest(b, sKey, W, a.roco_k1, sHist, ekv_fkey(1e9f));      // feasible set
+    EKW_TSTAMP(3);
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int j = tid + it * kNT;
@@ -128,6 +148,7 @@ __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int 
     [[clang::always_inline]] blk_mark_k_smallest(b, sKey, W, k, sHist);
   }
 
+  EKW_TSTAMP(4);
   // slot-map cells of the owned columns: requested now, consumed behind the scan's barriers
   int32_t cell[ITEMS];
 #pragma unroll
@@ -164,6 +185,7 @@ __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int 
     __syncthreads();       // (also: every thread's cell loads have completed before any thread stores to the slot map)
   }
 
+  EKW_TSTAMP(5);
   // ---- 4. write back from the registers: compacted score rows, evict ids (ascending), compacted slot map -----------------------
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
@@ -191,4 +213,5 @@ __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int 
       a.score_cnt[head_row + W - k + i] = (float)i * a.count_tail_step;
     }
   }
+  EKW_TSTAMP(6);
 }

@@ -1,0 +1,112 @@
+"""The scorer of a two-pass wide chunk step as the TAIL of the column-sum pass (easykv_amd/csrc/ekv_wide_tail.h, round 5) against
+the stand-alone scorer launch it replaces (``phases = 1`` then ``phases = 2``: the same attention launches, then
+ekv_score_select_kernel) on a twin bank: evicted ids, slot map and score rows must be EQUAL bit for bit — same column sums, same
+order of the sums, exact selects on both sides — over several consecutive steps (the tail's selects are warm-started from the
+head's previous thresholds), plain and RoPE-on-read keys, GQA, unsplit heads (the head's own workgroup scores it) and key-range
+splits (the last workgroup to arrive does).  The stand-alone scorer is pinned to the oracle / the reference's fixtures by
+tests/test_hip_prefill_parity.py, tests/test_hip_fullsize_configs.py and tests/test_hip_wide_kernel.py.
+
+Reference: accumulate easykv/easykv.py:443-457, select :462-490, compaction :465-490 / :56-82."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # d, hq, h, n, t_prev, n_split, policy, streaming
+    (128, 4, 4, 96, 1200, 1, "roco", False),        # configs[3]-shaped: 96 rows, unsplit
+    (128, 4, 4, 96, 5002, 1, "roco", False),        # ... at its full width (W = 5098: 20 columns per thread)
+    (128, 4, 4, 96, 1200, 0, "roco", False),        # library-chosen splits (few heads: several workgroups per head, last arriver scores)
+    (128, 4, 4, 96, 2100, 4, "roco", False),
+    (128, 8, 2, 16, 1232, 1, "h2o_head", False),    # configs[2]-shaped: Mistral GQA x4, 64 folded rows (2 x 2 waves)
+    (128, 8, 2, 16, 1232, 2, "roco", False),
+    (64, 4, 4, 64, 700, 1, "roco", False),
+    (128, 4, 4, 96, 900, 1, "roco", True),          # configs[4]-shaped: RoPE-on-read (keeps the stand-alone scorer: equal trivially, 3 launches)
+    (128, 4, 4, 96, 900, 3, "h2o_head", True),
+    (128, 16, 2, 12, 400, 1, "roco", False),        # GQA x8 (run-time fold)
+    (128, 4, 4, 40, 5, 1, "roco", False),           # a tiny cache: sentinels inside the feasible set
+]
+
+
+def _bank(L, hq, h, d, T, n, t_prev, k, v, streaming, seed):
+    from easykv_amd import KVBank
+    g = torch.Generator().manual_seed(seed)
+    bank = KVBank(L, hq, h, d, cap=T + 64)
+    if streaming:
+        from easykv_amd.api import rope_tables
+        bank.set_rope(*rope_tables(T + 64, d))
+    if t_prev:
+        bank.load_rows(k[:, :, :t_prev].cuda(), v[:, :, :t_prev].cuda())
+        perm = torch.argsort(torch.rand(L, h, t_prev, generator=g), dim=-1).int().cuda()
+        kk, vv = bank.k.clone(), bank.v.clone()
+        idx = perm.long().unsqueeze(-1).expand(-1, -1, -1, d)
+        bank.k[:, :, :t_prev].scatter_(2, idx, kk[:, :, :t_prev])
+        bank.v[:, :, :t_prev].scatter_(2, idx, vv[:, :, :t_prev])
+        bank.slot_of_pos[:, :, :t_prev] = perm
+    bank.state_init(T, 2, n)
+    return bank
+
+
+@pytest.mark.parametrize("d,hq,h,n,t_prev,n_split,policy,streaming", SHAPES)
+def test_tail_equals_the_stand_alone_scorer(d, hq, h, n, t_prev, n_split, policy, streaming):
+    from easykv_amd import StepPlan
+    L, T, steps = 3, t_prev + n, 6
+    g = torch.Generator().manual_seed(7 * d + 13 * hq + n + t_prev)
+    k = torch.randn(L, h, t_prev + n * steps, d, generator=g).half()
+    v = torch.randn(L, h, t_prev + n * steps, d, generator=g).half()
+    q = torch.randn(L, hq, n * steps, d, generator=g).half()
+    a = _bank(L, hq, h, d, T, n, t_prev, k, v, streaming, 5)
+    b = _bank(L, hq, h, d, T, n, t_prev, k, v, streaming, 5)
+    budget_p = t_prev + n
+    sink = 4 if t_prev > 100 else 0
+    plan = StepPlan(policy=policy, phase="prefill", accumulate=True, evict=t_prev > 0, budget=budget_p, recent=int(budget_p * 0.1), sink=sink, stride=n,
+                    n_split=n_split, two_pass=1, streaming=streaming)
+    info = a.step_info(plan, n)
+    assert info["wide"] == 1 and info["two_pass"] == 1
+    if streaming:
+        assert info["n_launches"] == 3, info          # RoPE-on-read keeps the stand-alone scorer (two workgroups per CU: a tail there costs stream)
+    elif info["n_split"] * info["n_col_parts"] == 1:
+        assert info["n_launches"] == 2, info          # one pass + column-sum pass with the scorer as its tail
+    else:
+        assert info["n_launches"] == 3, info          # ... + the fold of the key-range partials
+    for s in range(steps if t_prev > 0 else 1):
+        sl = slice(t_prev + s * n, t_prev + (s + 1) * n)
+        qs, ks, vs = q[:, :, s * n:(s + 1) * n].cuda().contiguous(), k[:, :, sl].cuda().contiguous(), v[:, :, sl].cuda().contiguous()
+        oa, ia = a.attend(plan, qs, ks, vs)                                   # whole step: the tail scores
+        ob = torch.empty_like(oa)
+        ib = torch.empty(L, h, n, dtype=torch.int32, device="cuda") if plan.evict else None
+        b.attend(plan, qs, ks, vs, out=ob, evict_ids=ib, phases=1)            # attention launches only
+        b.attend(plan, qs, ks, vs, out=ob, evict_ids=ib, phases=2)            # fold + stand-alone scorer
+        assert torch.equal(oa, ob), s
+        if plan.evict:
+            assert torch.equal(ia, ib), (s, (ia != ib).nonzero()[:4].tolist())
+        assert a.n_slots == b.n_slots
+        assert torch.equal(a.slot_of_pos, b.slot_of_pos), s
+        assert torch.equal(a.score_sum, b.score_sum) and torch.equal(a.score_sq, b.score_sq) and torch.equal(a.score_cnt, b.score_cnt), s
+    assert int(a.arrive.abs().sum()) == 0               # the arrival counters are back at zero
+
+
+def test_tail_on_a_broad_score_distribution_and_exact_ties():
+    """Keys with log-normal norms (score keys spread over decades: crowded histogram bins, refinement levels) and a block of IDENTICAL
+    cached rows (exact ties in mean and std: the tie rule 'lower position first' decides) — still equal to the stand-alone scorer."""
+    from easykv_amd import StepPlan
+    L, hq, h, d, n, t_prev, steps = 2, 4, 4, 128, 96, 3000, 5
+    g = torch.Generator().manual_seed(99)
+    T = t_prev + n
+    k = torch.randn(L, h, t_prev + n * steps, d, generator=g)
+    k = (k * torch.exp(1.2 * torch.randn(L, h, k.shape[2], 1, generator=g))).half()
+    k[:, :, 500:900] = k[:, :, 500:501]                 # 400 identical rows
+    v = torch.randn(L, h, t_prev + n * steps, d, generator=g).half()
+    q = torch.randn(L, hq, n * steps, d, generator=g).half()
+    a = _bank(L, hq, h, d, T, n, t_prev, k, v, False, 6)
+    b = _bank(L, hq, h, d, T, n, t_prev, k, v, False, 6)
+    plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=T, recent=int(T * 0.1), sink=4, stride=n, n_split=1, two_pass=1)
+    for s in range(steps):
+        sl = slice(t_prev + s * n, t_prev + (s + 1) * n)
+        qs, ks, vs = q[:, :, s * n:(s + 1) * n].cuda().contiguous(), k[:, :, sl].cuda().contiguous(), v[:, :, sl].cuda().contiguous()
+        oa, ia = a.attend(plan, qs, ks, vs)
+        ob, ib = torch.empty_like(oa), torch.empty_like(ia)
+        b.attend(plan, qs, ks, vs, out=ob, evict_ids=ib, phases=1)
+        b.attend(plan, qs, ks, vs, out=ob, evict_ids=ib, phases=2)
+        assert torch.equal(ia, ib), s
+        assert torch.equal(a.slot_of_pos, b.slot_of_pos) and torch.equal(a.score_sum, b.score_sum) and torch.equal(a.score_cnt, b.score_cnt), s
