@@ -23,17 +23,33 @@ class _ProbeLog:
     def __init__(self):
         self.gen = torch.Generator().manual_seed(11)
         self.unstable = []
+        self.inputs = []       # per selection: what it takes to re-run the UNSTABLE heads' decision (round 5: see in_tolerance_class)
+
+    def _alt(self, fn, policy, s, q, c, args, dim):
+        e1 = 1.0 + (torch.rand(s.shape, generator=self.gen) * 2 - 1) * self.PERT
+        e2 = 1.0 + (torch.rand(s.shape, generator=self.gen) * 2 - 1) * self.PERT
+        alt = fn(policy, s * e1, q * e2, c.clone(), *args)
+        return alt.unsqueeze(-1) if alt.dim() < dim else alt
 
     def __call__(self, fn, policy, s, q, c, args, ids):
         base = torch.sort(ids, dim=-1)[0]
         bad = torch.zeros(ids.shape[:-1], dtype=torch.bool)
         for _ in range(2):
-            e1 = 1.0 + (torch.rand(s.shape, generator=self.gen) * 2 - 1) * self.PERT
-            e2 = 1.0 + (torch.rand(s.shape, generator=self.gen) * 2 - 1) * self.PERT
-            alt = fn(policy, s * e1, q * e2, c.clone(), *args)
-            alt = alt.unsqueeze(-1) if alt.dim() < ids.dim() else alt
-            bad |= (torch.sort(alt, dim=-1)[0] != base).any(dim=-1)
+            bad |= (torch.sort(self._alt(fn, policy, s, q, c, args, ids.dim()), dim=-1)[0] != base).any(dim=-1)
         self.unstable.append(bad)
+        rows = bad.reshape(-1).nonzero().flatten()
+        flat = lambda x: x.reshape(-1, x.shape[-1])[rows].clone()
+        self.inputs.append(dict(fn=fn, policy=policy, args=args, rows=rows.tolist(), s=flat(s), q=flat(q), c=flat(c), dim=ids.dim()))
+
+    def in_tolerance_class(self, j, flat_row, got_sorted, tries=96):
+        """Is ``got_sorted`` one of the ORACLE'S OWN answers for that head under a +-2e-5 perturbation of its scores?"""
+        x = self.inputs[j]
+        i = x["rows"].index(flat_row)
+        for _ in range(tries):
+            alt = torch.sort(self._alt(x["fn"], x["policy"], x["s"][i:i + 1], x["q"][i:i + 1], x["c"][i:i + 1], x["args"], 2), dim=-1)[0][0]
+            if torch.equal(alt, got_sorted):
+                return True
+        return False
 
 
 def _report_stable(what, n_stable, n_dec, frac, floor):
@@ -51,11 +67,11 @@ def _report_stable(what, n_stable, n_dec, frac, floor):
         pass
 
 
-# Floors of the BOUND fraction per config.  The fraction is a property of the ORACLE and the seeded inputs (how many decisions the
-# reference itself flips under +-2e-5, with a head dropped at its first such draw), not of the HIP path — every bound decision must
-# match whatever the fraction is.  Measured (round 4, gpurun_out/stable_fractions.txt): configs[1] and [2] 1.0000 / >= 0.95,
-# configs[3] 453/485 = 0.934 and configs[4] 550/590 = 0.932: a 96-victim draw out of ~5000 columns has a threshold pair within 2e-5
-# in about one of 25 draws, and a head leaves the count at its first one.
+# Floor of the BOUND fraction (0.95 for every config).  Round 4 dropped a head at its first UNSTABLE draw (one the oracle itself flips
+# under +-2e-5: about one 96-victim draw of 25 at ~5000 columns), which bound 93 % of configs[3] / [4].  Round 5: a head leaves only
+# when the two sides actually DECIDED differently on such a draw — and that decision must still be one of the oracle's own answers
+# under +-2e-5 (in_tolerance_class); unstable draws both sides resolve alike stay bound.  tests/test_hip_lockstep.py re-seeds the
+# oracle from the bank every step instead and binds 100 % of the decisions at the same geometries.
 def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaForCausalLM", min_stable=0.95):
     import easykv_amd
     from oracle import easykv_oracle as O
@@ -85,7 +101,7 @@ def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaFo
     per_head = [e for e in tr.evictions if e["kind"] == "per_head"]
     assert len(per_head) == len(probe.unstable) and len(cache.evictions) == len(tr.evictions)
     alive = torch.ones(n_layers, h, dtype=torch.bool)
-    n_dec = n_stable = 0
+    n_dec = n_stable = n_class = 0
     j = 0
     for step, (ev, ours) in enumerate(zip(tr.evictions, cache.evictions)):
         got = torch.sort(torch.stack(ours).cpu().long(), dim=-1)[0]
@@ -94,25 +110,33 @@ def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaFo
             assert bool((got == torch.arange(lo, hi)).all()), step
             continue
         ref = torch.sort(ev["ids"].long(), dim=-1)[0]
-        ok = ~probe.unstable[j]
-        j += 1
+        ok = ~probe.unstable[j].reshape(got.shape[:-1])
         same = (got == ref).all(dim=-1)
         n_dec += int(alive.sum())
-        n_stable += int((alive & ok).sum())
+        n_stable += int((alive & (ok | same)).sum())      # bound: well defined and equal, or an unstable draw both sides resolved alike
         assert bool(same[alive & ok].all()), f"eviction {step}: stable decisions differ"
-        alive &= ok & same
+        # round 5: an unstable draw that came out DIFFERENTLY must still be one of the oracle's own answers under +-2e-5 — the head
+        # then leaves the comparison (its cache differs from here on); one that came out the same keeps being compared
+        for l, hh in (alive & ~ok & ~same).nonzero().tolist():
+            assert probe.in_tolerance_class(j, l * h + hh, got[l, hh]), f"eviction {step} layer {l} head {hh}: outside the oracle's tolerance class"
+            n_class += 1
+        j += 1
+        alive &= same
     frac = float(n_stable) / max(n_dec, 1)
     _report_stable(f"{mode} stride={stride} L={n_layers} Hq={hq} H={h} S={length} {cfg.get('kv_policy')}"
                    f"{' streaming' if cfg.get('streaming') else ''}{' keep_attention' if cfg.get('keep_attention') else ''}", n_stable, n_dec, frac, min_stable)
     assert n_dec > 0 and frac >= min_stable, (n_stable, n_dec, frac, min_stable)
 
-    # attention outputs: every forward until the first divergence of any head is comparable; the dense prefix and the
-    # first chunk always are
-    first_div = len(model.outputs_log) if bool(alive.all()) else 2
+    # attention outputs of EVERY forward for the query heads whose KV head never left the oracle's trajectory (round 4 compared the
+    # first two forwards only once any head had diverged); the dense prefix and the first chunk for all heads
     assert len(model.outputs_log) == len(ref_model.outputs_log)
-    for f in range(min(first_div, len(model.outputs_log))):
+    keep_q = alive.repeat_interleave(hq // h, dim=1)          # [layers, Hq]
+    for f in range(len(model.outputs_log)):
         a, b = model.outputs_log[f], ref_model.outputs_log[f]
-        assert out_close(a, b, OUT_TOL), (f, float((a - b).abs().max()))
+        if f < 2:
+            assert out_close(a, b, OUT_TOL), (f, float((a - b).abs().max()))
+        else:
+            assert out_close(a[keep_q], b[keep_q], OUT_TOL), (f, float((a[keep_q] - b[keep_q]).abs().max()))
     return res, tr, frac
 
 
@@ -156,7 +180,7 @@ def test_config4_llama13b_heads_ppl_streaming_stride96_full_geometry():
     ratio = 4096 / 10253
     assert geometry("ppl", 10253, ratio, 96) == (4192, 4109, 77)
     cfg = dict(budget=ratio, kv_policy="roco", streaming=True, temp_length=4, recent_ratio=0.1)
-    res, tr, frac = _run_pair("ppl", 96, cfg, 1, 40, 40, 128, 10253, seed=1313, min_stable=0.92)
+    res, tr, frac = _run_pair("ppl", 96, cfg, 1, 40, 40, 128, 10253, seed=1313)
     assert tr.cache_len == 4109
     assert abs(res - float(tr.result)) <= 1e-6 * abs(float(tr.result))
 
@@ -170,7 +194,7 @@ def test_config3_vicuna_passkey_stride96_full_geometry():
     from easykv_amd import geometry
     assert geometry("encoding", 9994, 0.5, 96) == (5093, 5002, 4906)
     cfg = dict(budget=0.5, kv_policy="roco", max_new_tokens=3, temp_length=4, recent_ratio=0.1)
-    res, tr, frac = _run_pair("encoding", 96, cfg, 1, 32, 32, 128, 9994, seed=9994, min_stable=0.92)
+    res, tr, frac = _run_pair("encoding", 96, cfg, 1, 32, 32, 128, 9994, seed=9994)
     assert tr.report.strip() == "KV cache budget ratio: 50.05%(5002/9994)"
     assert tr.cache_len == 5002 + 3
     assert res == " ".join(str(t) for t in tr.result)
