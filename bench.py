@@ -240,7 +240,7 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="enco
                          "bytes_per_step": by["total"] * L, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic": (traffic / (by["total"] * L)) if traffic else None,
                          "timing": "one HIP event pair around the timed chunk steps / steps (launches back to back)"},
-            "chunk_steps_timed": n_chunks, "slot_map": "identity" if args.identity_layout else "scattered"}
+            "chunk_steps_timed": n_chunks, "steps_run": 2 * warm + n_chunks + 8, "slot_map": "identity" if args.identity_layout else "scattered"}
 
 
 def prefill_pipeline(args, dev, rank, world, DS, S=9994, stride=96, n_chunks=32, warm=6):
@@ -255,7 +255,7 @@ def prefill_pipeline(args, dev, rank, world, DS, S=9994, stride=96, n_chunks=32,
     H = args.kv_heads or Hq
     shard = DS.LayerShard(rank, world, args.layers)
     Ls = shard.count
-    k = seqs_per_launch(max(1, args.layers // world), H, args.seqs_per_launch)      # in-flight sequences (prompts) whose chunk steps share a launch; one value for the job
+    k = seqs_per_launch(max(1, args.layers // world), H, args.seqs_per_launch, min_heads=512)      # in-flight sequences (prompts) whose chunk steps share a launch; one value for the job
     L = Ls * k
     bp, idx, _ = geometry("encoding", S, 0.5, stride)
     g = torch.Generator(device=dev).manual_seed(4321 + rank)
@@ -377,15 +377,17 @@ def live_pmc_step(script_args, script, timeout_s=150, env=None):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ekv_pmc_", dir="/tmp")
         try:
+            # (the child says how many steps it ran: since round 5 a wide step has no scorer launch of its own to count them by)
+            steps_file = os.path.join(d, "steps.txt")
             subprocess.run([rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, script] + script_args, cwd="/tmp",
-                           env=dict(os.environ, TMPDIR="/tmp", **(env or {})), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
+                           env=dict(os.environ, TMPDIR="/tmp", BENCH_CHUNK_STEPS_OUT=steps_file, **(env or {})), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == ctr and any(n in r["Kernel_Name"] for n in names)] if fs else []
+            steps = int(open(steps_file).read()) if os.path.exists(steps_file) else 0
         except Exception as e:
             shutil.rmtree(d, ignore_errors=True)
             return None, f"live PMC pass failed ({type(e).__name__})"
         shutil.rmtree(d, ignore_errors=True)
-        steps = sum(1 for r in rows if "ekv_score_select_kernel" in r["Kernel_Name"])
         if steps < 4:
             return None, f"live PMC pass saw {steps} steps"
         tot[ctr] = sum(float(r["Counter_Value"]) for r in rows) / steps
@@ -414,7 +416,10 @@ def prefill_pmc(S, stride, L, Hq, H, D, policy):
         if one:       # the whole step is one launch
             return one[0]["hbm_bytes_per_launch"], f"profiles/{os.path.basename(f)} [{stem}]: one launch per step"
         two = [v for n, v in ks.items() if "ekv_attn_chunk_kernel" in n or "ekv_attn_wide_kernel" in n or "ekv_score_select_kernel" in n]
-        steps = [v["launches"] for n, v in ks.items() if "ekv_score_select_kernel" in n]
+        # steps of the profiled run = launches of the one pass (mode 0 instance `<.., 0>` of the wide-block kernel: once per step); a
+        # summary from before round 5 counts them by the scorer launches (every step had one)
+        steps = ([v["launches"] for n, v in ks.items() if "ekv_attn_wide_kernel" in n and n.rstrip().endswith(", 0>")] or
+                 [v["launches"] for n, v in ks.items() if "ekv_score_select_kernel" in n])
         if two and steps:
             # launches per step from the launch counts: the two passes of the two-pass scheme may carry the same
             # kernel name (one template, two translation units), so that entry is the mean of the two and counts twice per step
@@ -529,15 +534,17 @@ def streaming_decode(args, dev, budget, policy):
                          "note": "algorithmic bytes exclude the rotation tables (L2-resident)"}}
 
 
-def seqs_per_launch(n_layers_of_rank, n_kv_heads, want=0):
+def seqs_per_launch(n_layers_of_rank, n_kv_heads, want=0, min_heads=256):
     """In-flight sequences a pipeline stage serves per launch.  A stage that owns few layers launches few heads (N = 8: 4 layers x 32
     = 128 heads, half a head per CU: the fused one-launch step needs >= 256, ekv_abi.hip) — but the pipeline holds >= N sequences in
     flight anyway, and the bank is generic in its layer count: (sequence, layer) pairs are just more layers.  Default:
-    the fewest sequences (1, 2, 4 ...) that put >= 256 heads into the launch."""
+    the fewest sequences (1, 2, 4 ...) that put >= ``min_heads`` heads into the launch: 256 for decode steps (one 8-wave workgroup
+    per CU), 512 for wide chunk steps (two workgroups per CU with unsplit heads, whose scorer then runs as the tail of the
+    column-sum pass: measured 0.31 of the HBM peak at 256 heads x 2 key-range splits)."""
     if want > 0:
         return want
     k = 1
-    while k * n_layers_of_rank * n_kv_heads < 256 and k < 8:
+    while k * n_layers_of_rank * n_kv_heads < min_heads and k < 8:
         k *= 2
     return k
 
@@ -675,7 +682,7 @@ def stage_workloads(args, dev, budget, policy):
             del bank
             return ev[0].elapsed_time(ev[1]) / n * 1e-3, n_split, fused
 
-        k = seqs_per_launch(Ls, H)
+        k = seqs_per_launch(Ls, H, min_heads=512)
         t, n_split, fused = chunk_stage(k)
         gbs = by["total"] * Ls * k / t / 1e9
         e = {"workload": f"configs[3] chunk step of a 4-layer stage (one rank of N=8), {k} in-flight sequence(s) per launch: S={S} stride={stride} T={idx + stride} "

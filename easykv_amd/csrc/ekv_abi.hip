@@ -661,13 +661,13 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   if (fuse_chunk) *one_launch = 1;
   // Two-pass step on the wide-block kernel (whole step, or the flush of a layer-per-call step whose column-sum pass was deferred):
   // the scorer runs as the TAIL of the column-sum pass (ekv_wide_tail.h, round 5) — score rows in registers, keys in the pass's
-  // tile buffers, four workgroups per CU — instead of a 1024-thread-per-CU scorer launch behind it.  A head whose column sums come
-  // from several workgroups (key-range splits / query-block groups) is scored by the last of them to arrive (bank->arrive).
+  // tile buffers, four workgroups per CU — instead of a 1024-thread-per-CU scorer launch behind it.  Only for heads whose column sums
+  // come from one workgroup (no key-range splits, one query-block group): split heads keep the stand-alone scorer (measured faster).
   // Not with RoPE-on-read: those passes run two workgroups per CU, where a head's ~50 us tail costs more stream than the launch it saves.
   const bool flush_colsum = (ph & 8) && !(ph & 1) && n > 1 && ws.q_keep != nullptr;
   const int tail_wgs = ws.n_split * ws.n_col_parts;
   const bool tail_step = n > 1 && ws.wide && ws.two_pass && (ph == 0 || flush_colsum) && ws.big_rows == nullptr && scored && st->accumulate &&
-                         st->policy != EKV_POLICY_TOVA && !st->rope_on_read && ekv_wide_tail_supported(W, tail_wgs, bank->arrive != nullptr);
+                         st->policy != EKV_POLICY_TOVA && !st->rope_on_read && ekv_wide_tail_supported(W, tail_wgs);
 
   // How the step ends, decided BEFORE anything is launched: a shape no scorer can take must be refused while the bank is
   // still untouched (the attention kernel appends the new rows).
@@ -717,7 +717,6 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
     if (tail_step && ph == 0) {
       // one pass (output / partials + row statistics) -> fold of the key-range partials, if any -> column-sum pass with the scorer as
       // its tail: two launches for an unsplit head
-      if (tail_wgs > 1) aa.arrive = bank->arrive + (size_t)st->layer_begin * bank->n_kv_heads;
       sa.skip_fold = 1;
       if (ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, true, s, nullptr, 1) != hipSuccess) return EKV_E_LAUNCH;
       if (!ws.fold_in_kernel && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
@@ -751,7 +750,6 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
     a2.q = ws.q_keep;
     a2.q_keep = nullptr;
     a2.new_in_cache = 1;
-    if (tail_step && tail_wgs > 1) a2.arrive = bank->arrive + (size_t)st->layer_begin * bank->n_kv_heads;
     if (ekv_launch_attn_chunk(a2, bank->head_dim, st->layer_count, true, s, nullptr, 2, tail_step ? &sa : nullptr) != hipSuccess) return EKV_E_LAUNCH;
     if (tail_step) return EKV_OK;
   }

@@ -102,11 +102,11 @@ int ekv_chunk_col_parts(int qpw, bool rope) { (void)rope; return qpw == 4 ? 4 : 
 
 // fuse_sc != nullptr: one-pass step with unsplit heads whose scorer runs as the tail of the attention kernel (no second launch)
 // The scorer as the tail of the wide column-sum pass holds the score rows of a head in registers (24 columns per thread of a
-// 256-thread workgroup) and the selection keys in the pass's tile buffers; heads written by several workgroups need the bank's
-// arrival counters
-bool ekv_wide_tail_supported(int W, int n_wg, bool have_arrive) {
+// 256-thread workgroup) and the selection keys in the pass's tile buffers; only heads whose column sums come from ONE workgroup
+// (a last-arriver election for split heads was built and measured slower than the stand-alone scorer: ekv_wide_tail.h)
+bool ekv_wide_tail_supported(int W, int n_wg) {
   static const bool off = [] { const char* e = std::getenv("EKV_NO_WIDE_TAIL"); return e != nullptr && e[0] == '1'; }();     // (A/B switch)
-  return !off && W >= 1 && W <= 24 * 256 && (n_wg == 1 || (have_arrive && n_wg <= 256));
+  return !off && W >= 1 && W <= 24 * 256 && n_wg == 1;
 }
 
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,

@@ -60,7 +60,7 @@ struct EkvAttnArgs {
   __half* q_keep;
   int32_t new_in_cache;
   // column-sum pass of the wide-block kernel: 1 = the scorer of the step runs as the tail of this launch (ekv_wide_tail.h; the
-  // EkvScoreArgs are the launch's second argument); heads written by several workgroups elect the last arriver through `arrive`
+  // EkvScoreArgs are the launch's second argument); set only for heads whose column sums ONE workgroup writes
   int32_t score_tail;
 };
 
@@ -100,7 +100,7 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
                                  const EkvScoreArgs* fuse_sc = nullptr, int passes = 3, const EkvScoreArgs* tail_sc = nullptr);
 // can the scorer of a two-pass wide step run as the tail of its column-sum pass: W score columns, n_wg workgroups per head
-bool ekv_wide_tail_supported(int W, int n_wg, bool have_arrive);
+bool ekv_wide_tail_supported(int W, int n_wg);
 size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs& a);
 bool ekv_score_rows_exceed_lds(int W, int rows);   // generic scorer: S / Q / C + keys of W columns do not fit 160 KB of LDS
 bool ekv_chunk_two_pass(int head_dim, int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode);

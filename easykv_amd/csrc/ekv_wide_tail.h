@@ -20,8 +20,13 @@
 // registers against the pass's 128-register bound (four workgroups per CU) — 51-85 spilled registers, every phase of the tail 1.5-3x
 // slower (177 k cycles per head) — and in the RoPE builds, which have the registers, the tail took the same 147 us as this version:
 // the chain of ~40 workgroup barriers and its memory round trips, not the LDS sweeps of the selects, is what a head's tail costs.
-// A head whose column sums come from SEVERAL workgroups (key-range splits, query-block groups: launches of few heads) is scored by the
-// last of them to arrive (ekv_bank.arrive, the protocol of the split decode kernel): see ekw_tail_arrive below.
+// Only for heads whose column sums come from ONE workgroup (unsplit heads, one query-block group: every 32-layer launch of the BASELINE
+// shapes).  Built, measured and removed: a last-arriver election (ekv_bank.arrive: workgroup barrier, agent-scope release by one lane,
+// one atomic per workgroup, acquire in the elected one) for heads split over key ranges — bit-identical (tests/test_hip_wide_tail.py ran
+// it), and SLOWER than the stand-alone scorer wherever it applied: the 8-layer configs[3] stage (256 heads x 2 splits) 320.6 vs 296.9 us,
+// one layer per call with the column-sum pass deferred to the flush (1024 heads x 8 splits) 65.3 vs 56.6 us per layer, stride 64 39.3 vs
+// 30.0 — a release fence in every workgroup of the launch, and the elected workgroup holds its slot for the ~50 us of a tail while the
+// head's other workgroups have long left.
 #pragma once
 
 // Included after ekv_score_select.inc (EKV_SS_NT 256, EKV_SS_DEVICE_ONLY): Blk, blk_mark_k_smallest, kNT, kNWV.
@@ -30,27 +35,6 @@ constexpr int kTailItems = 24;                       // owned columns per thread
 
 __host__ __device__ inline size_t ekw_tail_lds_bytes(int W) {      // keys | reduction scratch | histogram | candidate list
   return ekv_align((size_t)W * 4, 16) + 2 * 4 * 8 * 4 + 264 * 4 + 256 * 8;
-}
-
-// Last-arriver election for heads whose column sums are written by `n_wg` workgroups of this launch: every workgroup's sums are
-// complete in memory (agent-scope release by one lane behind a workgroup barrier), ONE atomic per workgroup on the head's counter;
-// the workgroup that observes n_wg - 1 resets the counter for the next launch, acquires, and runs the tail.  -> true in every
-// thread of the elected workgroup.
-__device__ __forceinline__ bool ekw_tail_arrive(uint32_t* counter, const int n_wg, uint32_t* s_flag) {
-  __syncthreads();                                   // every thread's column-sum stores are issued and (vmcnt(0)) complete
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (MI355X_MICROARCH.md: hipcc may drop the wait behind the write-back)
-    const uint32_t seen = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = seen == (uint32_t)(n_wg - 1);
-    if (last) {
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    *s_flag = last ? 1u : 0u;
-  }
-  __syncthreads();
-  return *s_flag != 0u;
 }
 
 template <int ITEMS>
