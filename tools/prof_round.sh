@@ -3,7 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md: they do not fit one pass; never combined with a trace)
 # for the decode bench and for each strided-prefill shape.  Raw outputs -> gpurun_out/prof_$TAG; tools/summarize_prof.py
 # condenses them into profiles/${TAG}_*.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -25,12 +25,20 @@ for cfg in "c2 4096 8 24" "s64 4096 64 12" "c4 9994 96 8"; do
   run_pmc chunk_$1_fetch FETCH_SIZE python $R/tools/bench_chunk.py $2 $3 $4
   run_pmc chunk_$1_write WRITE_SIZE python $R/tools/bench_chunk.py $2 $3 $4
 done
+# BASELINE configs[2]: Mistral GQA (8 KV heads), stride 16, budget 0.3
+BUDGET=0.3 run_pmc chunk_c3m_fetch FETCH_SIZE python $R/tools/bench_chunk.py 4096 16 12 8
+BUDGET=0.3 run_pmc chunk_c3m_write WRITE_SIZE python $R/tools/bench_chunk.py 4096 16 12 8
 # BASELINE configs[4]: Llama2-13B heads, ppl geometry, streaming RoPE-on-read
 export MODE=ppl BUDGET=0.39949283136642936 STREAMING=1 SHAPE=40,40,40
 run_pmc chunk_c5_fetch FETCH_SIZE python $R/tools/bench_chunk.py 10253 96 6
 run_pmc chunk_c5_write WRITE_SIZE python $R/tools/bench_chunk.py 10253 96 6
 unset MODE BUDGET STREAMING SHAPE
 timeout 600 bash $R/tools/sq_counters.sh > $OUT/sq_counters.txt 2>&1
+# cycle stamps of the scorer tail of the wide column-sum pass (a -DEKV_TAIL_PROFILE build of the m2 translation units, made in the build
+# container: tools/experiments/build_variant.sh tailprof "-DEKV_TAIL_PROFILE" ekv_attn_wide_d128_m2.hip)
+if [ -f $R/easykv_amd/csrc/variants/lib_tailprof.so ]; then
+  EASYKV_HIP_LIB=$R/easykv_amd/csrc/variants/lib_tailprof.so timeout 300 python $R/tools/experiments/exp_widetail_prof.py c3 s64 c2 > $OUT/wide_tail_stamps.txt 2>&1
+fi
 cd $R
 timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 ls $OUT

@@ -70,7 +70,8 @@ def main(src, tag):
     pre = {}
     algo = dict(c2=("S=4096 stride=8 budget=0.5 (configs[1]): T=2064", 35663872 * 32), s64=("S=4096 stride=64: T=2176", None),
                 c4=("S=9994 stride=96 budget=0.5 (configs[3] shape): T=5098", None),
-                c5=("S=10253 stride=96 ppl geometry, streaming RoPE-on-read, L=Hq=H=40 (configs[4] shape): T=4205", None))
+                c5=("S=10253 stride=96 ppl geometry, streaming RoPE-on-read, L=Hq=H=40 (configs[4] shape): T=4205", None),
+                c3m=("S=4096 stride=16 budget=0.3, 8 KV heads x GQA 4 (configs[2] shape): T=1248", None))
     for stem, (desc, _) in algo.items():
         c = combine(src, "chunk_" + stem)
         if c:
@@ -93,6 +94,11 @@ def main(src, tag):
         with open(f"profiles/{tag}_sq_counters.txt", "w") as fo:
             fo.write("# rocprofv3 --pmc (counters only, two passes) over tools/bench_prefix.py and tools/bench_chunk.py: tools/sq_counters.sh\n")
             fo.write(open(sq).read())
+    ts = os.path.join(src, "wide_tail_stamps.txt")
+    if os.path.exists(ts) and os.path.getsize(ts):
+        with open(f"profiles/{tag}_wide_tail_stamps.txt", "w") as fo:
+            fo.write("# cycle stamps (s_memtime) per head of the scorer tail of the wide column-sum pass, -DEKV_TAIL_PROFILE build: tools/experiments/exp_widetail_prof.py\n")
+            fo.write("".join(ln for ln in open(ts) if "amdgpu.ids" not in ln))
     for name, d in (("decode", dec["pmc"]), ("prefill", {k: {kk: vv["hbm_bytes_per_launch"] for kk, vv in v["kernels"].items()} for k, v in pre.items()})):
         print(name, json.dumps(d, indent=1)[:1800])
 
