@@ -233,3 +233,40 @@ def test_bench_refuses_to_label_fewer_ranks_as_n_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=root, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+
+
+def test_step_info_launch_counts_of_the_baseline_shapes():
+    """ekv_step_info is a dry run (no GPU, no memory touched): the dispatch decisions of the BASELINE shapes, incl. `n_launches` (ABI 7).
+    A two-pass wide step with unsplit heads is TWO launches since round 5 (the scorer is the tail of the column-sum pass,
+    easykv_amd/csrc/ekv_wide_tail.h; reference easykv/easykv.py:443-499); split heads and RoPE-on-read keep the scorer launch."""
+    from easykv_amd import _lib
+    from easykv_amd._lib import Bank
+    from easykv_amd.api import geometry
+    from easykv_amd.engine import KVBank, StepPlan
+
+    def bank(L, Hq, H, D, cap, n):
+        b = KVBank.__new__(KVBank)
+        b.lib = _lib.load()
+        cap = (cap + 63) // 64 * 64
+        b.n_layers, b.n_q_heads, b.n_kv_heads, b.head_dim, b.cap = L, Hq, H, D, cap
+        b._bank = Bank(256, 256, 256, 256, 256, 256, L, Hq, H, D, cap, 256, 256, 256)       # (dummy non-null pointers: nothing is dereferenced)
+        b.n_slots, b.extent, b._slot_rows, b._score_sum = [n] * L, [n] * L, [False] * L, True
+        return b
+
+    def chunk(L, Hq, H, S, stride, mode="encoding", budget=0.5, streaming=False, lc=None):
+        bp, idx, _ = geometry(mode, S, budget, stride)
+        plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=bp, recent=int(bp * 0.1), sink=4, stride=stride, streaming=streaming)
+        return bank(L, Hq, H, 128, idx + stride, idx).step_info(plan, stride, 0, lc)
+
+    c1 = chunk(32, 32, 32, 4096, 8)
+    assert (c1["fused"], c1["n_launches"]) == (1, 1)                                   # configs[1]: the logits-in-LDS kernel
+    for info in (chunk(32, 32, 8, 4096, 16, budget=0.3), chunk(32, 32, 32, 9994, 96), chunk(16, 32, 32, 9994, 96)):
+        assert (info["wide"], info["two_pass"], info["n_split"], info["n_launches"]) == (1, 1, 1, 2), info      # configs[2], [3], a 16-pair stage
+    one = chunk(32, 32, 32, 9994, 96, lc=1)
+    assert one["n_split"] > 1 and one["n_launches"] == 3                               # one layer per call: split heads keep the scorer launch
+    c4 = chunk(40, 40, 40, 10253, 96, "ppl", 4096 / 10253, True)
+    assert (c4["wide"], c4["two_pass"], c4["n_launches"]) == (1, 1, 3)                 # configs[4]: RoPE-on-read keeps it too
+    b = bank(32, 32, 32, 128, 2049 + 63, 2048)
+    dec = StepPlan(policy="roco", phase="decode", evict=True, score_off=0, budget=2048)
+    assert (b.step_info(dec, 1)["fused"], b.step_info(dec, 1)["n_launches"]) == (1, 1)
+    assert b.step_info(dec, 1, 0, 4)["n_launches"] == 2 and b.step_info(dec, 1, 0, 8)["fused"] == 1      # 128 heads: attention + scorer; 256: the 8-wave fused kernel
