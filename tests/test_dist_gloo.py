@@ -36,9 +36,10 @@ def _worker(rank, world, port, n_layers, out_q):
         D.ring_handoff(hidden, recv, shard)     # every rank takes part in every exchange (ring)
         D.barrier()
     t = D.max_over_ranks(float(r + 1))
+    seen, per_rank = D.sum_over_ranks(1.0), D.all_gather_floats(10.0 * r + 1.0)      # bench.py: ranks_seen, per-rank us_per_step
     # plain lists, not tensors: a tensor crosses a torch.multiprocessing queue as a shared-memory handle, and the parent fails
     # with EOFError if this process has exited before the handle is opened (seen once under load)
-    out_q.put((r, shard.begin, shard.end, hidden.flatten().tolist(), recv.flatten().tolist(), t))
+    out_q.put((r, shard.begin, shard.end, hidden.flatten().tolist(), recv.flatten().tolist(), (t, seen, per_rank)))
     D.barrier()
     torch.distributed.destroy_process_group()
 
@@ -75,7 +76,7 @@ def test_two_rank_pipeline_handoff():
     assert (b0, e0, b1, e1) == (0, 3, 3, 6)
     assert torch.allclose(h1, ref)            # the last stage holds the full-depth result
     assert torch.allclose(recv0, h1)          # ...and the ring returns it to stage 0 (next token's input)
-    assert t0 == t1 == 2.0                    # max over ranks
+    assert t0 == t1 == (2.0, 2.0, [1.0, 11.0])       # max over ranks; ranks seen by an all-reduce of ones; one float per rank, in rank order
 
 
 def _worker_async(rank, world, port, steps, out_q):
