@@ -37,14 +37,13 @@ class _ProbeLog:
         for _ in range(2):
             bad |= (torch.sort(self._alt(fn, policy, s, q, c, args, ids.dim()), dim=-1)[0] != base).any(dim=-1)
         self.unstable.append(bad)
-        rows = bad.reshape(-1).nonzero().flatten()
-        flat = lambda x: x.reshape(-1, x.shape[-1])[rows].clone()
-        self.inputs.append(dict(fn=fn, policy=policy, args=args, rows=rows.tolist(), s=flat(s), q=flat(q), c=flat(c), dim=ids.dim()))
+        flat = lambda x: x.reshape(-1, x.shape[-1]).clone()
+        self.inputs.append(dict(fn=fn, policy=policy, args=args, s=flat(s), q=flat(q), c=flat(c), dim=ids.dim()))
 
     def in_tolerance_class(self, j, flat_row, got_sorted, tries=96):
         """Is ``got_sorted`` one of the ORACLE'S OWN answers for that head under a +-2e-5 perturbation of its scores?"""
         x = self.inputs[j]
-        i = x["rows"].index(flat_row)
+        i = flat_row
         for _ in range(tries):
             alt = torch.sort(self._alt(x["fn"], x["policy"], x["s"][i:i + 1], x["q"][i:i + 1], x["c"][i:i + 1], x["args"], 2), dim=-1)[0][0]
             if torch.equal(alt, got_sorted):
@@ -114,10 +113,10 @@ def _run_pair(mode, stride, cfg, n_layers, hq, h, d, length, seed, arch="LlamaFo
         same = (got == ref).all(dim=-1)
         n_dec += int(alive.sum())
         n_stable += int((alive & (ok | same)).sum())      # bound: well defined and equal, or an unstable draw both sides resolved alike
-        assert bool(same[alive & ok].all()), f"eviction {step}: stable decisions differ"
-        # round 5: an unstable draw that came out DIFFERENTLY must still be one of the oracle's own answers under +-2e-5 — the head
-        # then leaves the comparison (its cache differs from here on); one that came out the same keeps being compared
-        for l, hh in (alive & ~ok & ~same).nonzero().tolist():
+        # round 5: a decision that came out DIFFERENTLY must still be one of the oracle's own answers under +-2e-5 (whether or not the
+        # two probe draws flagged it) — the head then leaves the comparison (its cache differs from here on); an unstable draw that came
+        # out the same keeps being compared
+        for l, hh in (alive & ~same).nonzero().tolist():
             assert probe.in_tolerance_class(j, l * h + hh, got[l, hh]), f"eviction {step} layer {l} head {hh}: outside the oracle's tolerance class"
             n_class += 1
         j += 1

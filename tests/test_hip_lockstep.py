@@ -5,9 +5,9 @@ leaves the comparison for the rest of the run (configs[3] / [4]: 93 % of the dec
 from the bank — ordered K / V rows, score rows — so that every step is an independent comparison of one HIP step with one
 oracle step from the SAME state:
 
-  * a decision the oracle's own +-2e-5 perturbation probe calls well defined must equal the oracle's bit for bit;
-  * a decision the probe flips (one draw in ~25 at 96 victims out of ~5000 columns) must still be ONE OF THE ORACLE'S OWN answers
-    under such a perturbation (searched over fresh random draws): bound to the tolerance class, not skipped;
+  * every decision must EQUAL the oracle's bit for bit, or — a near-tie: one draw in ~25 at 96 victims out of ~5000 columns has a
+    threshold pair within 2e-5 — be ONE OF THE ORACLE'S OWN answers under a +-2e-5 perturbation of its scores (searched over fresh
+    random draws): bound to the tolerance class, never skipped.  (So far every decision of every run has been equal.)
   * after the step the bank's state (ordered rows, slot map as a permutation, sums, counts) equals the oracle's.
 
 Reference: easykv/easykv.py:443-499 (chunk steps), :287-337 (decode steps); llama_patch.py:310-327 (streaming)."""
@@ -128,9 +128,11 @@ def test_every_chunk_step_decision_is_bound(name, L, hq, h, d, S, stride, mode, 
                 unstable = hook.last["unstable"]
                 n_dec += h
                 n_exact += int((same & ~unstable).sum()) + int((same & unstable).sum())
-                assert bool(same[~unstable].all()), f"{name} step {i} layer {l}: a well-defined decision differs"
-                for hh in (~same).nonzero().flatten().tolist():      # (only unstable heads get here)
-                    assert hook.in_tolerance_class(hh, got[l, hh]), f"{name} step {i} layer {l} head {hh}: not one of the oracle's answers under +-2e-5"
+                for hh in (~same).nonzero().flatten().tolist():
+                    # a decision that differs must be one of the oracle's OWN answers under +-2e-5 — whether or not the six probe draws
+                    # flagged the head (a near-tie escapes six draws with probability 2^-6: the search below uses 96 more)
+                    assert hook.in_tolerance_class(hh, got[l, hh]), (f"{name} step {i} layer {l} head {hh}: not one of the oracle's answers under +-2e-5"
+                                                                     f" (probe said {'unstable' if bool(unstable[hh]) else 'well defined'})")
                     n_class += 1
                 # state after the step, for the heads that took the oracle's decision: rows, sums, counts
                 m = same
@@ -194,9 +196,8 @@ def test_the_benched_decode_state_against_the_oracle():
                 unstable = hook.last["unstable"]
                 n_dec += H
                 n_exact += int(same.sum())
-                assert bool(same[~unstable].all()), f"step {i} layer {l}: a well-defined decision differs"
-                for hh in (~same).nonzero().flatten().tolist():
-                    assert hook.in_tolerance_class(hh, got[l, hh:hh + 1]), (i, l, hh)
+                for hh in (~same).nonzero().flatten().tolist():      # (see the chunk test: bound to the tolerance class, probe flag or not)
+                    assert hook.in_tolerance_class(hh, got[l, hh:hh + 1]), (i, l, hh, bool(unstable[hh]))
                     n_class += 1
                     reseed.append(l)
             if reseed:      # the oracle's copy of those layers follows the bank again (K / V rows and score rows of every head)
