@@ -131,7 +131,18 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
     // pass over K
 #define EKW_GO(d, m, aa, t) (rope ? ekv_launch_attn_wide_rope_d##d##_m##m(aa, nwq, layer_count, s, t) : ekv_launch_attn_wide_d##d##_m##m(aa, nwq, layer_count, s, t))
     hipError_t e = hipSuccess;
-    if (passes & 1) e = head_dim == 128 ? EKW_GO(128, 0, a, nullptr) : EKW_GO(64, 0, a, nullptr);
+    if (passes & 1) {
+      // a launch of at most one workgroup per CU (a layer-per-call model) runs 65..128-row blocks on 128-key tiles, 8 waves
+      static const bool no_big = [] { const char* ev = std::getenv("EKV_NO_BIG_TILE"); return ev != nullptr && ev[0] == '1'; }();     // (A/B switch)
+      const bool small = (size_t)layer_count * a.n_kv_heads * a.n_split * a.n_qblocks <= 256;
+      const int nwq_keep = nwq;
+      const int nwq0 = (!rope && nwq == 4 && small && !no_big) ? 8 : nwq;
+      {
+        const int nwq = nwq0;
+        e = head_dim == 128 ? EKW_GO(128, 0, a, nullptr) : EKW_GO(64, 0, a, nullptr);
+      }
+      (void)nwq_keep;
+    }
     if (two_pass && (passes & 2) && e == hipSuccess) {
       EkvAttnArgs a2 = a;
       a2.score_tail = tail_sc != nullptr ? 1 : 0;
