@@ -665,7 +665,11 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // come from one workgroup (no key-range splits, one query-block group): split heads keep the stand-alone scorer (measured faster).
   // Not with RoPE-on-read: those passes run two workgroups per CU, where a head's ~50 us tail costs more stream than the launch it saves.
   const bool flush_colsum = (ph & 8) && !(ph & 1) && n > 1 && ws.q_keep != nullptr;
-  const int tail_wgs = ws.n_split * ws.n_col_parts;
+  // The flush's column-sum launch covers ALL deferred layers: with >= 512 (head, layer, query-block group) units it runs UNSPLIT whatever
+  // key-range split the one-layer calls of the one pass used (that split exists to fill the chip from 32 heads) — 1024 workgroups in one
+  // resident round instead of 8192 short ones, and the scorer as its tail.
+  const bool flush_unsplit = flush_colsum && ws.wide && ws.two_pass && (size_t)st->layer_count * bank->n_kv_heads * ws.n_col_parts >= 512;
+  const int tail_wgs = (flush_unsplit ? 1 : ws.n_split) * ws.n_col_parts;
   const bool tail_step = n > 1 && ws.wide && ws.two_pass && (ph == 0 || flush_colsum) && ws.big_rows == nullptr && scored && st->accumulate &&
                          st->policy != EKV_POLICY_TOVA && !st->rope_on_read && ekv_wide_tail_supported(W, tail_wgs);
 
@@ -750,6 +754,11 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
     a2.q = ws.q_keep;
     a2.q_keep = nullptr;
     a2.new_in_cache = 1;
+    if (flush_unsplit) {
+      a2.n_stat_parts = ws.n_split;
+      a2.n_split = 1;
+      a2.rows_per_split = ws.t_pad;
+    }
     if (ekv_launch_attn_chunk(a2, bank->head_dim, st->layer_count, true, s, nullptr, 2, tail_step ? &sa : nullptr) != hipSuccess) return EKV_E_LAUNCH;
     if (tail_step) return EKV_OK;
   }

@@ -62,6 +62,7 @@ struct EkvAttnArgs {
   // column-sum pass of the wide-block kernel: 1 = the scorer of the step runs as the tail of this launch (ekv_wide_tail.h; the
   // EkvScoreArgs are the launch's second argument); set only for heads whose column sums ONE workgroup writes
   int32_t score_tail;
+  int32_t n_stat_parts;     // column-sum pass: (max, sum) partials per query row in `stats` when that differs from this launch's n_split (0 = n_split)
 };
 
 struct EkvScoreArgs {
