@@ -20,6 +20,11 @@
 // registers against the pass's 128-register bound (four workgroups per CU) — 51-85 spilled registers, every phase of the tail 1.5-3x
 // slower (177 k cycles per head) — and in the RoPE builds, which have the registers, the tail took the same 147 us as this version:
 // the chain of ~40 workgroup barriers and its memory round trips, not the LDS sweeps of the selects, is what a head's tail costs.
+// Also built and withdrawn: warm-started selects on the LDS keys (window around the head's previous threshold key: one counting / listing
+// sweep, a reduction, one ranking, one marking sweep — 2 sweeps + 4 barriers instead of 5 + 8).  The std select hit its window in 99.5 % of
+// the heads at the configs[3] shape (90 % stride 64, 78 % configs[2]) and took the SAME 18 k cycles; the mean select (its threshold jumps
+// when the 96 smallest leave) missed every time.  With 16 waves per CU in the same phase at once the tail is bound by VALU issue — ~12
+// instructions per key and sweep — not by the barrier chain: fewer instructions per key would help, fewer barriers do not.
 // Only for heads whose column sums come from ONE workgroup (unsplit heads, one query-block group: every 32-layer launch of the BASELINE
 // shapes).  Built, measured and removed: a last-arriver election (ekv_bank.arrive: workgroup barrier, agent-scope release by one lane,
 // one atomic per workgroup, acquire in the elected one) for heads split over key ranges — bit-identical (tests/test_hip_wide_tail.py ran

@@ -56,6 +56,8 @@ if __name__ == "__main__":
     if "s96" in sel: run(4096, 96)
     if "c2" in sel: run(4096, 16, H=8, budget=0.3)
     if "c4" in sel: run(10253, 96, L=40, Hq=40, H=40, mode="ppl", budget=4096 / 10253, streaming=True)
+    if "s64w" in sel: run(4096, 64, which=("whole_step",))
+    if "c3w" in sel: run(9994, 96, which=("whole_step",))
     if "l1c3" in sel: run(9994, 96, L=1, which=("mode0_full",))
     if "l1" in sel:
         run(9994, 96, L=1)
