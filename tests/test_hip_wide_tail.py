@@ -107,3 +107,38 @@ def test_tail_on_a_broad_score_distribution_and_exact_ties():
         b.attend(plan, qs, ks, vs, out=ob, evict_ids=ib, phases=2)
         assert torch.equal(ia, ib), s
         assert torch.equal(a.slot_of_pos, b.slot_of_pos) and torch.equal(a.score_sum, b.score_sum) and torch.equal(a.score_cnt, b.score_cnt), s
+
+
+def test_launches_of_more_than_one_workgroup_per_cu_keep_the_four_wave_tiles():
+    """Round 5 runs launches of at most 256 workgroups (a layer-per-call model) on 128-key tiles with 4 x 2 waves; everything else in this
+    file is such a launch.  288 heads (9 layers x 32) take the 64-key, 4-wave shape the 32-layer bench launches run on: whole step (tail)
+    against attention launches + stand-alone scorer on a twin bank, and the attention output of one layer against the oracle."""
+    from easykv_amd import StepPlan
+    from oracle import easykv_oracle as O
+    from tests.golden_util import out_close
+    L, hq, h, d, n, t_prev, steps = 9, 32, 32, 128, 96, 700, 3
+    T = t_prev + n
+    g = torch.Generator().manual_seed(4242)
+    k = torch.randn(L, h, t_prev + n * steps, d, generator=g).half()
+    v = torch.randn(L, h, t_prev + n * steps, d, generator=g).half()
+    q = torch.randn(L, hq, n * steps, d, generator=g).half()
+    a = _bank(L, hq, h, d, T, n, t_prev, k, v, False, 8)
+    b = _bank(L, hq, h, d, T, n, t_prev, k, v, False, 8)
+    plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=T, recent=int(T * 0.1), sink=4, stride=n, two_pass=1)
+    info = a.step_info(plan, n)
+    assert info["wide"] == 1 and info["n_split"] == 1 and info["n_launches"] == 2
+    for s in range(steps):
+        sl = slice(t_prev + s * n, t_prev + (s + 1) * n)
+        qs, ks, vs = q[:, :, s * n:(s + 1) * n].cuda().contiguous(), k[:, :, sl].cuda().contiguous(), v[:, :, sl].cuda().contiguous()
+        if s == 0:      # the oracle's attention over the same (scattered) cache: layer 4
+            kk, vv = a.ordered_kv(4, 1)
+            o_ref, _ = O.attention_core(q[4:5, :, :n].float(), torch.cat([kk.float().cpu(), k[4:5, :, sl].float()], 2),
+                                        torch.cat([vv.float().cpu(), v[4:5, :, sl].float()], 2), O.causal_chunk_mask(n, T, torch.float32))
+        oa, ia = a.attend(plan, qs, ks, vs)
+        ob, ib = torch.empty_like(oa), torch.empty_like(ia)
+        b.attend(plan, qs, ks, vs, out=ob, evict_ids=ib, phases=1)
+        b.attend(plan, qs, ks, vs, out=ob, evict_ids=ib, phases=2)
+        if s == 0:
+            assert out_close(oa[4].float().cpu(), o_ref[0]), float((oa[4].float().cpu() - o_ref[0]).abs().max())
+        assert torch.equal(oa, ob) and torch.equal(ia, ib), s
+        assert torch.equal(a.slot_of_pos, b.slot_of_pos) and torch.equal(a.score_sum, b.score_sum) and torch.equal(a.score_cnt, b.score_cnt), s
