@@ -171,7 +171,18 @@ def event_overhead_us(dev, reps=32):
     return v[len(v) // 2]
 
 
-def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="encoding", budget=0.5, streaming=False, shape=None, pmc=True):
+def prewarm(step, seconds, dev):
+    """Untimed pre-warm of a secondary figure: the same step for `seconds` of wall time.  A launch shape timed right after its first
+    use runs at lower clocks for hundreds of milliseconds (DESIGN.md §3.5 'a measurement trap': configs[3] 903 us per step behind 8
+    warm-up steps, 857-863 us behind >= 25 ms of them) — the headline run has had --prewarm-s since round 1."""
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize(dev)
+
+
+def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="encoding", budget=0.5, streaming=False, shape=None, pmc=True, prewarm_s=0.25):
     """Secondary figures (never `value`): the chunk phase of a strided prefill (SURVEY.md §8d Bench-P).  Default = BASELINE.json
     configs[1]: S=4096, stride 8, budget 0.5, kv_policy roco; also run at stride 64 / 96 and at the configs[3] shape
     (S=9994, stride 96).  The cache oscillates idx <-> idx+stride, every chunk step attends the retained slots with `stride`
@@ -202,6 +213,8 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="enco
     ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
     # whole step as the library runs it (phases = 0: one launch when the scorer fuses into the attention kernel) ...
     # (one HIP-event pair around the timed region: a pair per step costs ~8 us of marker latency, see event_overhead_us)
+    if prewarm_s > 0:      # clocks and score state settle on fresh inputs of the same distribution (new rows every step, like the timed ones)
+        prewarm(lambda: bank.attend(plan, rnd(Hq, stride), rnd(H, stride), rnd(H, stride), out=out, evict_ids=ids), prewarm_s, dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for i in range(warm + n_chunks):
         if i == warm:
@@ -240,7 +253,7 @@ def strided_prefill(args, dev, n_chunks=48, warm=8, S=4096, stride=8, mode="enco
                          "bytes_per_step": by["total"] * L, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic": (traffic / (by["total"] * L)) if traffic else None,
                          "timing": "one HIP event pair around the timed chunk steps / steps (launches back to back)"},
-            "chunk_steps_timed": n_chunks, "steps_run": 2 * warm + n_chunks + 8, "slot_map": "identity" if args.identity_layout else "scattered"}
+            "chunk_steps_timed": n_chunks, "prewarm_s": prewarm_s, "steps_run": 2 * warm + n_chunks + 8, "slot_map": "identity" if args.identity_layout else "scattered"}
 
 
 def prefill_pipeline(args, dev, rank, world, DS, S=9994, stride=96, n_chunks=32, warm=6):
@@ -670,7 +683,8 @@ def stage_workloads(args, dev, budget, policy):
             o = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
             ids = torch.empty(L, H, stride, dtype=torch.int32, device=dev)
             n_split, fused = bank.step_plan(plan, stride)
-            for j in range(24):
+            prewarm(lambda: bank.attend(plan, rnd(Hq, stride), rnd(H, stride), rnd(H, stride), out=o, evict_ids=ids), 0.2, dev)
+            for j in range(8):
                 bank.attend(plan, *ins[j % 4], out=o, evict_ids=ids)
             n = 48
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -725,15 +739,23 @@ def per_layer_chunk_steps(args, dev, S, stride, n_steps=6, warm=3, mode="encodin
         out = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
         views = [[(q[l:l + 1], k[l:l + 1], v[l:l + 1], out[l:l + 1]) for l in range(L)] for (q, k, v) in ins]
         t0 = 0.0
-        for i in range(warm + n_steps):
-            if i == warm:
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
+
+        def forward(i):
             for l in range(L):
                 q1, k1, v1, o1 = views[i % 2][l]
                 bank.attend(plan, q1, k1, v1, layer_begin=l, out=o1, defer=defer)
             if defer:
                 bank.flush()
+        t_end = time.perf_counter() + 0.15      # pre-warm (clocks): whole forwards
+        while time.perf_counter() < t_end:
+            forward(0)
+            forward(1)
+            torch.cuda.synchronize(dev)
+        for i in range(warm + n_steps):
+            if i == warm:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            forward(i)
         torch.cuda.synchronize(dev)
         res[name] = (time.perf_counter() - t0) / n_steps / L * 1e6
         del bank

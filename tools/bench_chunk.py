@@ -20,7 +20,8 @@ args = types.SimpleNamespace(layers=32, heads=32, kv_heads=kvh, head_dim=128, po
 # other BASELINE shapes: MODE=ppl BUDGET=0.3995 STREAMING=1 SHAPE=40,40,40 (layers, query heads, KV heads)
 shape = tuple(int(x) for x in os.environ["SHAPE"].split(",")) if os.environ.get("SHAPE") else None
 r = bench.strided_prefill(args, torch.device("cuda"), n_chunks=n_chunks, S=S, stride=stride, mode=os.environ.get("MODE", "encoding"),
-                          budget=float(os.environ.get("BUDGET", "0.5")), streaming=os.environ.get("STREAMING", "0") == "1", shape=shape, pmc=False)
+                          budget=float(os.environ.get("BUDGET", "0.5")), streaming=os.environ.get("STREAMING", "0") == "1", shape=shape, pmc=False,
+                          prewarm_s=float(os.environ.get("PREWARM_S", "0")))      # (0: counter runs need a known number of steps)
 if os.environ.get("BENCH_CHUNK_STEPS_OUT"):      # for bench.live_pmc_step: how many chunk steps this process ran (whole + split form)
     with open(os.environ["BENCH_CHUNK_STEPS_OUT"], "w") as f:
         f.write(str(r["steps_run"]))
