@@ -134,9 +134,11 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
     if (passes & 1) {
       // a launch of at most one workgroup per CU (a layer-per-call model) runs 65..128-row blocks on 128-key tiles, 8 waves
       static const bool no_big = [] { const char* ev = std::getenv("EKV_NO_BIG_TILE"); return ev != nullptr && ev[0] == '1'; }();     // (A/B switch)
-      const bool small = (size_t)layer_count * a.n_kv_heads * a.n_split * a.n_qblocks <= 256;
+      // (... and key ranges long enough to hold several 128-key tiles: measured per one-layer call, 64-key / 128-key tiles — 96 rows x 640 keys
+      //  per split 43.2 / 38.2 us; 64 rows x 272 keys 24.5 / 26.1; 32 layers x 8 KV heads x 1248 keys unsplit (configs[2]) 43.1 / 41.5)
+      const bool small = (size_t)layer_count * a.n_kv_heads * a.n_split * a.n_qblocks <= 256 && a.rows_per_split >= 512;
       const int nwq_keep = nwq;
-      const int nwq0 = (!rope && nwq == 4 && small && !no_big) ? 8 : nwq;
+      const int nwq0 = (!rope && small && !no_big) ? (nwq == 4 ? 8 : 9) : nwq;
       {
         const int nwq = nwq0;
         e = head_dim == 128 ? EKW_GO(128, 0, a, nullptr) : EKW_GO(64, 0, a, nullptr);
