@@ -129,7 +129,7 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
     const int nwq = qpw == 4 ? 4 : 2;
     // one pass over K and V (output, and for a scored step every row's softmax statistics), then — scored steps — the column-sum
     // pass over K
-#define EKW_GO(d, m, aa, t) (rope ? ekv_launch_attn_wide_rope_d##d##_m##m(aa, nwq, layer_count, s, t) : ekv_launch_attn_wide_d##d##_m##m(aa, nwq, layer_count, s, t))
+#define EKW_GO(d, m, aa, shape, t) (rope ? ekv_launch_attn_wide_rope_d##d##_m##m(aa, shape, layer_count, s, t) : ekv_launch_attn_wide_d##d##_m##m(aa, shape, layer_count, s, t))
     hipError_t e = hipSuccess;
     if (passes & 1) {
       // a launch of at most one workgroup per CU (a layer-per-call model) runs 65..128-row blocks on 128-key tiles, 8 waves
@@ -137,18 +137,13 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
       // (... and key ranges long enough to hold several 128-key tiles: measured per one-layer call, 64-key / 128-key tiles — 96 rows x 640 keys
       //  per split 43.2 / 38.2 us; 64 rows x 272 keys 24.5 / 26.1; 32 layers x 8 KV heads x 1248 keys unsplit (configs[2]) 43.1 / 41.5)
       const bool small = (size_t)layer_count * a.n_kv_heads * a.n_split * a.n_qblocks <= 256 && a.rows_per_split >= 512;
-      const int nwq_keep = nwq;
-      const int nwq0 = (!rope && small && !no_big) ? (nwq == 4 ? 8 : 9) : nwq;
-      {
-        const int nwq = nwq0;
-        e = head_dim == 128 ? EKW_GO(128, 0, a, nullptr) : EKW_GO(64, 0, a, nullptr);
-      }
-      (void)nwq_keep;
+      const int shape0 = (!rope && small && !no_big) ? (nwq == 4 ? 8 : 9) : nwq;      // workgroup-shape code of ekv_attn_wide.inc's entry (8 / 9: 128-key tiles)
+      e = head_dim == 128 ? EKW_GO(128, 0, a, shape0, nullptr) : EKW_GO(64, 0, a, shape0, nullptr);
     }
     if (two_pass && (passes & 2) && e == hipSuccess) {
       EkvAttnArgs a2 = a;
       a2.score_tail = tail_sc != nullptr ? 1 : 0;
-      e = head_dim == 128 ? EKW_GO(128, 2, a2, tail_sc) : EKW_GO(64, 2, a2, tail_sc);
+      e = head_dim == 128 ? EKW_GO(128, 2, a2, nwq, tail_sc) : EKW_GO(64, 2, a2, nwq, tail_sc);
     }
 #undef EKW_GO
     return e;
