@@ -1,4 +1,4 @@
-"""Dense causal prefix alone (bench.dense_prefix without the rest of the bench line): python tools/bench_prefix.py [tokens] [layers]"""
+"""Dense causal prefix alone (bench.dense_prefix without the rest of the bench line): [REPS=3] python tools/bench_prefix.py [tokens] [layers]"""
 import os
 import sys
 import time
@@ -15,7 +15,7 @@ D = 128
 dev = torch.device("cuda")
 g = torch.Generator(device=dev).manual_seed(0)
 q, k, v = (torch.randn(L, h, n, D, generator=g, device=dev).half() for h in (Hq, H, H))
-for rep in range(3):
+for rep in range(int(os.environ.get("REPS", 3))):
     bank = KVBank(L, Hq, H, D, cap=n + 8)
     torch.cuda.synchronize()
     t = time.perf_counter()
