@@ -63,6 +63,13 @@ def main(src, tag):
     dec = dict(command="rocprofv3 --kernel-trace --stats -- python bench.py --steps 512 --no-cpu-baseline ; rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE "
                        "-- python bench.py --no-cpu-baseline --steps 16 --warmup 4 --prewarm-s 0.05 --no-prefill --no-boundary",
                kernels=kernels, pmc=combine(src, "decode"))
+    ut = os.path.join(src, "bench_under_trace.log")      # the traced process's own bench line: its avg_launch_us is what the trace's average must agree with
+    if os.path.exists(ut):
+        lines = [ln for ln in open(ut) if ln.startswith("{")]
+        if lines:
+            open(f"profiles/{tag}_bench_line_under_trace.json", "w").write(lines[-1])
+            dec["bench_line_of_the_traced_process"] = {k: json.loads(lines[-1])[k] for k in ("value", "ms_per_step", "steps", "warmup")}
+            dec["bench_line_of_the_traced_process"]["roofline"] = json.loads(lines[-1])["roofline"]
     bl = os.path.join(src, "bench_line.json")
     if os.path.exists(bl) and os.path.getsize(bl):
         dec["bench_line_same_box"] = json.loads(open(bl).read().strip().splitlines()[-1])
