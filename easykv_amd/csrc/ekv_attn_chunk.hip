@@ -31,7 +31,8 @@ bool ekv_chunk_two_pass(int head_dim, int rep, int q_len, int policy, bool score
   const bool rep_ok = rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // rep query heads share a 16-lane row
   const bool can = q_len > 1 && scored && accumulate && policy != EKV_POLICY_TOVA && rep_ok;
   if (!can || mode < 0) return false;
-  // measured crossover: 32 rows 0.34 (one pass) vs 0.36 ms, 48 rows 0.42 vs 0.41 ms
+  // measured crossover: 32 rows 0.34 (one pass) vs 0.36 ms, 48 rows 0.42 vs 0.41 ms.  RoPE-on-read steps keep the two passes too (round 5,
+  // end): with the logits exported by the wide kernel's one pass and swept by the scorer, a configs[4] step is 2190 vs 2205 us
   return mode > 0 || ((!rope || head_dim == 64 || head_dim == 128) && rep * q_len >= 40);
 }
 
@@ -62,7 +63,8 @@ bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, 
   ekv_chunk_blocks(rep, q_len, &qb_rows, &n_qblocks, &qpw);
   if (qpw < 2) return false;                                  // <= 32 rows: HBM-bound shapes, the small-tile kernels
   if (two_pass) return rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16;   // the column-sum pass folds the rep query heads in registers
-  return !wants_logits;
+  // only the RoPE builds export logits, and only for single-block steps (every key of the range is visited) of a power-of-two GQA factor
+  return !wants_logits || (rope && n_qblocks == 1 && (rep == 1 || rep == 2 || rep == 4 || rep == 8 || rep == 16));
 }
 
 // rope_on_read: q' = q*cos[pos] + rotate_half(q)*sin[pos] with pos = T - n + i (llama_patch.py:311, :326), once per step,

@@ -206,3 +206,36 @@ def test_rope_on_read_steps_match_oracle(d, hq, h, n, t_prev, n_split, scored):
             assert torch.allclose(bank.score_sq[l, :, :T].cpu(), q_ref, rtol=COL_RTOL, atol=1e-9)
     kk, vv = bank.ordered_kv()
     assert torch.equal(kk.cpu(), k) and torch.equal(vv.cpu(), v)
+
+
+ONE_PASS_ROPE_SHAPES = [s for s in ROPE_SHAPES if s[1] // s[2] * s[3] <= 128]      # single query block: the wide RoPE one pass exports its logits
+
+
+@pytest.mark.parametrize("d,hq,h,n,t_prev,n_split", ONE_PASS_ROPE_SHAPES)
+def test_rope_on_read_one_pass_exports_logits_for_the_scorer(d, hq, h, n, t_prev, n_split):
+    """A scored RoPE-on-read step forced to ONE pass (StepPlan.two_pass = -1; what TOVA steps take by themselves): the wide-block kernel's
+    `REP = -1` instance exports the raw logits (quotient units) and the row statistics, the scorer rebuilds the probabilities from them
+    (easykv/easykv.py:443-457 over llama_patch.py:310-327) — same bounds against the fp32 oracle as the two-pass scheme."""
+    from easykv_amd import KVBank, StepPlan
+    from oracle import easykv_oracle as O
+    g = torch.Generator().manual_seed(17 * d + hq * 100 + n)
+    L, T = 2, t_prev + n
+    q = torch.randn(L, hq, n, d, generator=g).half()
+    k = torch.randn(L, h, T, d, generator=g).half()
+    v = torch.randn(L, h, T, d, generator=g).half()
+    cos, sin = O.rope_tables(T + 64, d)
+    bank = KVBank(L, hq, h, d, cap=T + 64, scored=True)
+    bank.set_rope(cos, sin)
+    _scatter_bank(bank, k, v, t_prev, g)
+    bank.state_init(T, 2, 1)
+    plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=False, n_split=n_split, two_pass=-1, streaming=True)
+    info = bank.step_info(plan, n)
+    assert info["wide"] == 1 and info["two_pass"] == 0
+    out, _ = bank.attend(plan, q.cuda(), k[:, :, t_prev:].cuda().contiguous(), v[:, :, t_prev:].cuda().contiguous())
+    for l in range(L):
+        o_ref, s_ref, q_ref = _ref_stream(q[l:l + 1], k[l:l + 1], v[l:l + 1], h, cos, sin)
+        assert out_close(out[l].float().cpu(), o_ref), float((out[l].float().cpu() - o_ref).abs().max())
+        assert torch.allclose(bank.score_sum[l, :, :T].cpu(), s_ref, rtol=COL_RTOL, atol=1e-7), float(((bank.score_sum[l, :, :T].cpu() - s_ref).abs() / s_ref.abs().clamp_min(1e-6)).max())
+        assert torch.allclose(bank.score_sq[l, :, :T].cpu(), q_ref, rtol=COL_RTOL, atol=1e-9)
+    kk, vv = bank.ordered_kv()
+    assert torch.equal(kk.cpu(), k) and torch.equal(vv.cpu(), v)

@@ -35,7 +35,8 @@ def run(S, stride, L=32, Hq=32, H=32, D=128, mode="encoding", budget=0.5, stream
         bank.slot_of_pos[:, :, :idx] = torch.argsort(torch.rand(L, H, idx, generator=g, device=dev), dim=-1).int()
         bank.state_init(idx + stride, 2, stride)
         plan = StepPlan(policy=pol, phase="prefill", accumulate=acc, evict=ev, budget=bp, recent=int(bp * 0.1), sink=4, stride=stride, streaming=streaming,
-                        n_split=int(os.environ.get("NSPLIT", "0")))      # (NSPLIT: force the key-range splits per head)
+                        n_split=int(os.environ.get("NSPLIT", "0")),      # (NSPLIT: force the key-range splits per head)
+                        two_pass=int(os.environ.get("TWO_PASS", "0")))      # (TWO_PASS=-1: one pass + exported logits, 1: column-sum pass, 0: the library decides)
         qs, ks, vs = [rnd(Hq, stride) for _ in range(3)], [rnd(H, stride) for _ in range(3)], [rnd(H, stride) for _ in range(3)]
         out = torch.empty(L, Hq, stride, D, dtype=torch.float16, device=dev)
         st = {"i": 0}
