@@ -41,6 +41,9 @@ struct EkvNoop {
 };
 // KU = rows in flight per lane group (K and V each): 8 (122 VGPRs in the fused kernel = four workgroups per CU).  16 is
 // supported for plain keys in logical order and was tried in the split kernel (ekv_attn_decode.inc): no gain.
+#ifndef EKV_ROPE_MOCK
+#define EKV_ROPE_MOCK 0      // experiment builds of the RoPE-on-read decode stream: 1 = no table loads, 2 = no partner exchange
+#endif
 template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4, bool PHYS = false, int KU = kU, typename MaskReady = EkvNoop>
 __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
                                                   int logit_stride, int t0, int t1_in, int ll, int h, size_t head_row,
@@ -82,17 +85,28 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   // group.  The row is rotated ONCE (fp32) and then dotted with each of the REP rotated queries.
   auto rope_key = [&](const uint4& kv, int j, float (&kp)[8]) {
     uint4 other;
+#if EKV_ROPE_MOCK == 2      // (mock: no partner exchange)
+    other = kv;
+#else
     other.x = __shfl_xor(kv.x, LPR / 2, 64);
     other.y = __shfl_xor(kv.y, LPR / 2, 64);
     other.z = __shfl_xor(kv.z, LPR / 2, 64);
     other.w = __shfl_xor(kv.w, LPR / 2, 64);
+#endif
     const ekv_h8 kh = __builtin_bit_cast(ekv_h8, kv), oh = __builtin_bit_cast(ekv_h8, other);
     // the tables are cat(freqs, freqs) (llama_patch.py:74-98; checked by KVBank.set_rope): both halves of the lane group read
     // the FIRST half of the row, so a wave touches half as many table lines — the loop moved 4x more table than K bytes
     // through the texture path (two fp32 tables against one fp16 row)
     const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)j * D + (sub % (LPR / 2)) * 8);
     const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)j * D + (sub % (LPR / 2)) * 8);
+#if EKV_ROPE_MOCK == 1      // (mock: no table loads — opaque constants, same arithmetic)
+    float one = 1.f, zero = 0.25f;
+    asm volatile("" : "+v"(one), "+v"(zero));
+    (void)c4; (void)s4;
+    const float4 c0 = make_float4(one, one, one, one), c1 = c0, s0 = make_float4(zero, zero, zero, zero), s1 = s0;
+#else
     const float4 c0 = c4[0], c1 = c4[1], s0 = s4[0], s1 = s4[1];
+#endif
     const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const float sgn = (sub < LPR / 2) ? -1.f : 1.f;
