@@ -260,7 +260,9 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
     eos_token_ids = cfg.get("eos_token_ids", [self.tokenizer.eos_token_id])
     streaming = cfg.get("streaming", False)
     record = cfg.get("_record_evictions", False)      # test hook: keep the evicted ids of every forward
-    use_graph = cfg.get("hipgraph", False)            # extension key: capture the steady-state decode step in a hipGraph
+    # extension key: capture the steady-state forwards — the evicting decode step and, round 6, the evicting strided chunk of the
+    # prefill — in a hipGraph each (GraphedForward)
+    use_graph = cfg.get("hipgraph", False)
     n_layers, hq, h, d = _dims(self)
     dev = torch.device(self.device)
     if input_ids.dim() != 2 or input_ids.shape[0] != 1:
@@ -401,35 +403,48 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
         def fed(self):   # tokens the reference would have fed back into the model (:257-264: the EOS token itself is not)
             return self.n - 1 if self.stopped_by_eos else self.n
 
-    class GraphedStep:
-        """One decode forward of the WHOLE model captured in a hipGraph.  At a fixed budget every decode
-        step that evicts has the same shapes, the same StepPlan and the same cache length before and after, so the host work
-        of a step (HF's per-layer Python, ~0.5 ms per layer) is paid once at capture and a token costs one graph launch.
-        Token id and position live in static device tensors; sampling and the EOS test stay outside the graph."""
+    class GraphedForward:
+        """One forward of the WHOLE model captured in a hipGraph — a decode step (one token), or, since round 6, a
+        strided chunk of the prefill (`stride` tokens).  At a fixed budget every evicting forward has the same shapes, the same
+        StepPlan and the same cache length before and after (the cache oscillates idx <-> idx + stride, easykv/easykv.py:426-433), so
+        the host work of a forward (HF's per-layer Python, ~0.4 ms per layer: 12 ms of a 13 ms chunk forward of a 32-layer model) is
+        paid once at capture and a forward costs one graph launch.  Token ids and positions live in static device tensors; sampling, the
+        EOS test and the collection of logits / evicted ids stay outside the graph."""
 
-        def __init__(self, cache, plan, tok, pos):
-            self.tok = tok.view(1, 1).clone()
-            self.pos = torch.full((1,), pos, dtype=torch.long, device=dev)
+        def __init__(self, cache, plan, tok, positions):
+            n = len(positions)
+            self.tok = tok.view(1, n).clone()
+            self.pos = torch.as_tensor(positions, dtype=torch.long).to(dev)
             self.graph = torch.cuda.CUDAGraph()
             plan.streaming = streaming
             self.cache = cache
+            n_recorded = len(cache.evictions)
             tk = _ACTIVE.set(cache)
             try:
-                with torch.cuda.graph(self.graph):      # capture launches nothing: the first replay runs this step
+                with torch.cuda.graph(self.graph):      # capture launches nothing: the first replay runs this forward
                     cache.begin_forward(plan, self.pos)
                     self.logits = self_model(input_ids=self.tok, past_key_values=cache, position_ids=self.pos.view(1, -1),
-                                             use_cache=True).logits[:, -1, :]
+                                             use_cache=True).logits
             finally:
                 _ACTIVE.reset(tk)
+            if cache.n_attend != cache.layer_count:
+                raise RuntimeError(f"model forward made {cache.n_attend} attend() calls for {cache.layer_count} owned layers")
+            # record=True: the captured forward left its (static) id tensors in the log; every replay appends a copy instead
+            self.static_ids = cache.evictions.pop() if len(cache.evictions) > n_recorded else None
             self.layout = cache.bank.layout_signature()     # the captured kernels are those of THIS score-row layout
 
-        def __call__(self, tok, pos):
+        def __call__(self, tok, positions):
             if self.cache.bank.layout_signature() != self.layout:
-                raise RuntimeError("the bank's score-row layout changed between capture and replay of the decode-step graph "
+                raise RuntimeError("the bank's score-row layout changed between capture and replay of the forward's graph "
                                    "(an eager call on the bank in between): capture again")
-            self.tok.copy_(tok.view(1, 1))
-            self.pos.fill_(pos)
+            self.tok.copy_(tok.view(self.tok.shape))
+            if len(positions) == 1:
+                self.pos.fill_(positions[0])
+            else:      # (consecutive positions, built on the device: no host-to-device copy on the replay path)
+                torch.arange(positions[0], positions[0] + len(positions), dtype=torch.long, device=dev, out=self.pos)
             self.graph.replay()
+            if self.static_ids is not None:
+                self.cache.evictions.append([t.clone() for t in self.static_ids])
             return self.logits
 
     self_model = self
@@ -461,10 +476,10 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                     plan.range_start = score_off + e
             # steady state (same plan, same cache length as the step before, one slot evicted per step): replay the graph
             sig = (t_now, evict, plan.range_start)
-            if use_graph and evict and policy != "random" and not record and sig == prev_sig:
+            if use_graph and evict and policy != "random" and sig == prev_sig:
                 if graphed is None:
-                    graphed = GraphedStep(cache, plan, tok, cur_pos)
-                logits_last = graphed(tok, cur_pos)
+                    graphed = GraphedForward(cache, plan, tok, [cur_pos])
+                logits_last = graphed(tok, [cur_pos])[:, -1, :]
             else:
                 logits_last = forward(cache, tok.view(1, 1), [cur_pos], plan).logits[:, -1, :]
             prev_sig = sig
@@ -485,6 +500,7 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
         logits_last = out.logits[:, -1, :]
         all_logits, all_ids = [], []
         cur_pos = r_idx
+        graphed, prev_sig = None, None
         for tok_i in range(r_idx, length, stride):                # :426
             t_now = cache.get_seq_length() + stride
             plan = StepPlan(policy=policy, phase="prefill", accumulate=scored and (t_now > idx or keep_attention),
@@ -494,10 +510,22 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
                 plan.range_start = sink                          # :491-493
             elif plan.evict and policy == "random":              # :494-499: argmax of torch.rand over the row, chunk excluded
                 plan.range_start = policy_draw(idx + stride, stride)
-            out = forward(cache, input_ids[:, tok_i:tok_i + stride], list(range(cur_pos, cur_pos + stride)), plan)
-            logits_last = out.logits[:, -1, :]
+            # steady state (generation_config['hipgraph']): from the second evicting chunk on every forward has the plan, the shapes and
+            # the cache length of the one before it — captured once, replayed for the rest of the prompt
+            sig = (t_now, plan.accumulate, plan.evict, plan.range_start)
+            chunk_ids, chunk_pos = input_ids[:, tok_i:tok_i + stride], list(range(cur_pos, cur_pos + stride))
+            if use_graph and plan.evict and policy != "random" and sig == prev_sig and chunk_ids.shape[1] == stride:
+                if graphed is None:
+                    graphed = GraphedForward(cache, plan, chunk_ids, chunk_pos)
+                logits = graphed(chunk_ids, chunk_pos)
+                if keep_logits:
+                    logits = logits.clone()      # (the graph's output buffer is overwritten by the next replay)
+            else:
+                logits = forward(cache, chunk_ids, chunk_pos, plan).logits
+            prev_sig = sig
+            logits_last = logits[:, -1, :]
             if keep_logits:
-                all_logits.append(out.logits[0])
+                all_logits.append(logits[0])
                 all_ids.append(input_ids[0, tok_i:tok_i + stride])
             cur_pos += stride
         cache.bank.release_workspace(keep_bytes=64 << 20)      # (deferred chunk steps keep all layers' logits / column sums: not the decode phase's business)

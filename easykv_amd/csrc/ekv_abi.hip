@@ -41,6 +41,7 @@ __global__ void ekv_rows_copy_kernel(__half* bank_k, __half* bank_v, const int32
   const size_t head_row = ((size_t)(layer_begin + ll) * n_kv_heads + h) * cap;
   const int lpr = D / 8;
   const int rows_per_block = blockDim.x / lpr;
+  if ((int)threadIdx.x >= rows_per_block * lpr) return;      // (head_dim 96: 21 rows of 12 pieces per 256 threads)
   const int sub = threadIdx.x % lpr;
   for (int i = blockIdx.x * rows_per_block + threadIdx.x / lpr; i < n; i += gridDim.x * rows_per_block) {
     const int row = slot[head_row + pos_begin + i];
@@ -72,7 +73,9 @@ __global__ void __launch_bounds__(256) ekv_compact_inplace_kernel(__half* k, __h
   char* base = reinterpret_cast<char*>((which == 0 ? k : v) + ((size_t)(layer_begin + ll) * n_kv_heads + h) * cap * D);
   for (int i = threadIdx.x; i < n_evict; i += 256) s_ev[i] = evict[((size_t)ll * n_kv_heads + h) * n_evict + i];
   __syncthreads();
-  const int lpr = D / 8, sub = threadIdx.x % lpr, rg = threadIdx.x / lpr, rpb = 256 / lpr;
+  const int lpr = D / 8, rpb = 256 / lpr;
+  const int tix = min((int)threadIdx.x, rpb * lpr - 1);      // (head_dim 96: the 4 threads past 21 rows x 12 pieces repeat the last piece)
+  const int sub = tix % lpr, rg = tix / lpr;
   const int first = s_ev[0], n_keep = n_slots - n_evict;
   const int row_bytes = D * 2;
   // source row of destination d = d + #{e : ev[e] - e <= d} (ev ascending, so ev[e] - e is non-decreasing: a branch-free binary
@@ -232,7 +235,7 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? EKV_OK : E
 int check_bank(const ekv_bank* b) {
   if (!b || !b->k || !b->v || !b->slot_of_pos) return EKV_E_ARG;
   if (b->n_layers <= 0 || b->n_kv_heads <= 0 || b->n_q_heads % b->n_kv_heads || b->cap <= 0) return EKV_E_ARG;
-  if (b->head_dim != 32 && b->head_dim != 64 && b->head_dim != 128) return EKV_E_UNSUPPORTED;
+  if (b->head_dim != 32 && b->head_dim != 64 && b->head_dim != 96 && b->head_dim != 128) return EKV_E_UNSUPPORTED;
   return EKV_OK;
 }
 
@@ -687,7 +690,8 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
 
   // decode split path whose partials are folded right behind the attention kernel (attention + fold phases, or a step that has
   // nothing to score): the last-arriving split of a head folds them inside the attention kernel — no fold launch
-  const bool fold_in_decode = n == 1 && bank->arrive != nullptr && (ph == 0 || (ph & 1)) && !ws.fold_in_kernel &&
+  // (GQA factors > 8 run several query-head groups per KV head, ekv_attn_decode.inc: the arrival counter counts one group's splits)
+  const bool fold_in_decode = n == 1 && rep <= 8 && bank->arrive != nullptr && (ph == 0 || (ph & 1)) && !ws.fold_in_kernel &&
                               ((ph & 4) || (ph == 0 && (fold_only || range_only)));
   if (plan_out) {      // kernel launches of this call (ekv_step_info): the same tests as the launch sequence below, in its order
     int nl = 0;

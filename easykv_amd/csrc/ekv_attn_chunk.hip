@@ -6,7 +6,7 @@
 
 #define EKV_DECL(d, m) hipError_t ekv_launch_attn_chunk_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t, const EkvScoreArgs*);
 EKV_DECL(32, 0) EKV_DECL(32, 1) EKV_DECL(32, 2) EKV_DECL(64, 0) EKV_DECL(64, 1) EKV_DECL(64, 2)
-EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
+EKV_DECL(96, 0) EKV_DECL(96, 1) EKV_DECL(96, 2) EKV_DECL(128, 0) EKV_DECL(128, 1) EKV_DECL(128, 2)
 #undef EKV_DECL
 
 #define EKW_DECL(d, m) hipError_t ekv_launch_attn_wide_d##d##_m##m(const EkvAttnArgs&, int, int, hipStream_t, const EkvScoreArgs*);
@@ -37,7 +37,7 @@ bool ekv_chunk_two_pass(int head_dim, int rep, int q_len, int policy, bool score
 }
 
 bool ekv_attn_chunk_supported(int head_dim, int rep, int q_len) {
-  return (head_dim == 32 || head_dim == 64 || head_dim == 128) && rep >= 1 && rep <= 128 && q_len >= 1;
+  return (head_dim == 32 || head_dim == 64 || head_dim == 96 || head_dim == 128) && rep >= 1 && rep <= 128 && q_len >= 1;
 }
 
 // A query block is <= 128 GQA-folded rows (rep x qb_rows).  qpw = 1 or 2: 16-row query tiles per wave of a 4-wave
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) ekv_rope_q_kernel(const EkvAttnArgs a, in
   // overhead per configs[4] step — 153 600 workgroups)
   const int tpr = D / 4, rpb = 256 / tpr;
   const int r_in = blockIdx.x * rpb + threadIdx.x / tpr;       // (q head, query) of this layer
-  if (r_in >= n_rows) return;
+  if (r_in >= n_rows || (int)threadIdx.x >= rpb * tpr) return;      // (head_dim 96: 10 rows of 24 threads)
   const size_t row = (size_t)blockIdx.y * n_rows + r_in;       // (layer, q head, query)
   const int i = r_in % a.q_len;
   const int pos = a.n_slots - a.q_len + i;
@@ -157,6 +157,7 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
   switch (head_dim) {
     case 32: e = two_pass ? EKV_GO(32, 1) : EKV_GO(32, 0); if (two_pass && e == hipSuccess) e = EKV_GO(32, 2); break;
     case 64: e = two_pass ? EKV_GO(64, 1) : EKV_GO(64, 0); if (two_pass && e == hipSuccess) e = EKV_GO(64, 2); break;
+    case 96: e = two_pass ? EKV_GO(96, 1) : EKV_GO(96, 0); if (two_pass && e == hipSuccess) e = EKV_GO(96, 2); break;
     case 128: e = two_pass ? EKV_GO(128, 1) : EKV_GO(128, 0); if (two_pass && e == hipSuccess) e = EKV_GO(128, 2); break;
     default: e = hipErrorInvalidValue;
   }

@@ -11,6 +11,7 @@
 typedef _Float16 ekv_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 ekv_h8 __attribute__((ext_vector_type(8)));
 typedef unsigned int ekv_u4 __attribute__((ext_vector_type(4)));
+typedef float ekv_f2 __attribute__((ext_vector_type(2)));
 
 template <int CTRL>
 __device__ __forceinline__ float ekv_dpp(float x) {

@@ -35,7 +35,9 @@ __global__ void __launch_bounds__(kSNT) ekv_decode_score_kernel(const EkvScoreAr
   red.lane = lane;
   red.wave = wave;
   const size_t head_row = ((size_t)(sc.layer_begin + ll) * sc.n_kv_heads + h) * sc.cap;
-  const size_t hq0 = (size_t)ll * sc.n_q_heads + (size_t)h * REP;
+  // REP = the GQA factor rounded up to 1 / 2 / 4 / 8 (ekv_attn_decode.inc); the padding rows repeat the last real head's logits
+  const int nrep = (REP == 1 || REP == 2) ? REP : sc.n_q_heads / sc.n_kv_heads;
+  const size_t hq0 = (size_t)ll * sc.n_q_heads + (size_t)h * nrep;
 
 #ifdef EKV_TAIL_PROFILE
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sc.tova_row) + ((size_t)ll * sc.n_kv_heads + h) * 8;
@@ -46,16 +48,16 @@ __global__ void __launch_bounds__(kSNT) ekv_decode_score_kernel(const EkvScoreAr
     const int full = t_pad / 256;
     for (int c = wave; c < full * REP; c += kSNW) {
       const int r = c / full, ch = c % full;
-      const float* src = sc.logits + (hq0 + r) * t_pad + ch * 256 + lane * 4;
+      const float* src = sc.logits + (hq0 + min(r, nrep - 1)) * t_pad + ch * 256 + lane * 4;
       __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(s_logit + (size_t)r * t_pad + ch * 256), 16, 0, 0);
     }
     for (int r = 0; r < REP; ++r)
-      for (int j = full * 256 + tid; j < t_pad; j += kSNT) s_logit[(size_t)r * t_pad + j] = sc.logits[(hq0 + r) * t_pad + j];
+      for (int j = full * 256 + tid; j < t_pad; j += kSNT) s_logit[(size_t)r * t_pad + j] = sc.logits[(hq0 + min(r, nrep - 1)) * t_pad + j];
   }
 
   // fold the key-range splits into the attention output
   const int PS = D + 2;
-  for (int idx = tid; idx < (sc.skip_fold ? 0 : REP * D); idx += kSNT) {
+  for (int idx = tid; idx < (sc.skip_fold ? 0 : nrep * D); idx += kSNT) {
     const int r = idx / D, d = idx % D;
     sc.out[(hq0 + r) * D + d] = __float2half(ekv_fold_partials_auto(sc.partials + ((hq0 + r) * sc.n_split) * PS, sc.n_split, PS, d));
   }
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(kSNT) ekv_decode_score_kernel(const EkvScoreAr
   EKV_STAMP(1);
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(red.buf + 2 * kSNW * 8);     // roco select scratch: histogram, candidate list
   unsigned long long* s_list = reinterpret_cast<unsigned long long*>(s_hist + 264);
-  ekv_decode_tail<REP, ITEMS, kSNW>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red, s_hist, s_list, kSNT);
+  ekv_decode_tail<REP, ITEMS, kSNW>(sc, ll, h, head_row, T, off, W, s_logit, t_pad, sS, sQ, sC, red, s_hist, s_list, kSNT, nullptr, 0, 0, nrep);
 }
 
 // Partials of the key-range splits -> fp16 attention output, nothing else (rows = q_len * n_q_heads per layer).
@@ -101,8 +103,8 @@ hipError_t launch_rep(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
 bool ekv_decode_score_supported(const EkvScoreArgs& sc) {
   const int rep = sc.n_q_heads / sc.n_kv_heads;
   if (sc.q_len != 1 || sc.n_evict > 1 || (sc.cap & 3) != 0 || sc.n_slots > 256 * 24) return false;
-  if (rep != 1 && rep != 2 && rep != 4 && rep != 8) return false;
-  return score_lds(rep, sc.t_pad, sc.policy) <= 150 * 1024;
+  if (rep < 1 || rep > 8) return false;      // (wider GQA factors: the generic scorer)
+  return score_lds(rep <= 2 ? rep : (rep <= 4 ? 4 : 8), sc.t_pad, sc.policy) <= 150 * 1024;
 }
 
 hipError_t ekv_launch_fold(const EkvScoreArgs& sc, int layer_count, hipStream_t s) {
@@ -114,8 +116,8 @@ hipError_t ekv_launch_decode_score(const EkvScoreArgs& sc, int layer_count, hipS
   switch (sc.n_q_heads / sc.n_kv_heads) {
     case 1: return launch_rep<1>(sc, layer_count, s);
     case 2: return launch_rep<2>(sc, layer_count, s);
-    case 4: return launch_rep<4>(sc, layer_count, s);
-    case 8: return launch_rep<8>(sc, layer_count, s);
+    case 3: case 4: return launch_rep<4>(sc, layer_count, s);
+    case 5: case 6: case 7: case 8: return launch_rep<8>(sc, layer_count, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -11,9 +11,12 @@
 
 constexpr int kU = 8;   // rows in flight per lane group (K and V each)
 
+// head_dim 96 (any head_dim that is a multiple of 16 but not a power of two): a row keeps a power-of-two lane group (LPR = 16) of
+// which only the first LIVE = D / 8 lanes hold a 16-byte piece; the idle lanes carry zeros through the dot products and reductions.
 template <int D, int NW = 4, int KU = kU>
 struct EkvDecodeGeom {
-  static constexpr int LPR = D / 8;   // lanes per row
+  static constexpr int LIVE = D / 8;  // lanes of a row's lane group that hold a 16-byte piece
+  static constexpr int LPR = LIVE <= 4 ? 4 : (LIVE <= 8 ? 8 : 16);   // lanes per row (power of two)
   static constexpr int G = 64 / LPR;  // rows per wave-load
   static constexpr int RW = G * KU;   // rows per wave per iteration
   static constexpr int NP = NW;       // partials per workgroup = waves (lane groups are combined in-wave)
@@ -48,9 +51,11 @@ template <int D, int REP, bool ROPE, bool SLOT_LDS, int NW = 4, bool PHYS = fals
 __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const int32_t* s_slot, float* logit_out,
                                                   int logit_stride, int t0, int t1_in, int ll, int h, size_t head_row,
                                                   float (&m)[REP], float (&l)[REP], float (&o)[REP][8],
-                                                  const uint8_t* s_dead = nullptr, MaskReady mask_ready = MaskReady()) {
+                                                  const uint8_t* s_dead = nullptr, MaskReady mask_ready = MaskReady(),
+                                                  int n_rep_real = 0, int q_head0 = -1) {
   using Gm = EkvDecodeGeom<D, NW, KU>;
-  constexpr int LPR = Gm::LPR, RW = Gm::RW;
+  constexpr int LPR = Gm::LPR, RW = Gm::RW, LIVE = Gm::LIVE;
+  constexpr bool PADDED = LIVE != LPR;      // head_dim 96: lanes sub >= LIVE of a lane group are idle (zero pieces, no loads / stores)
   constexpr int kNW = NW;
   static_assert(!(PHYS && (ROPE || SLOT_LDS)), "physical-order streaming: plain keys, global slot map");
   static_assert((KU == 4 || KU == 8 || KU == 16) && (!PHYS || KU <= 8), "4, 8 or 16 rows per lane group; the dead-row mask is one byte per 8 rows");
@@ -58,14 +63,22 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   const int sub = lane % LPR, grp = lane / LPR;
   const int t_new = a.n_slots - 1;  // the appended position
   int t1 = t1_in;
+  const bool live_lane = !PADDED || sub < LIVE;
+  // GQA factors that are not a power of two (or, in the split kernel, groups of <= 8 query heads of a wider factor): REP is the
+  // padded count, `nrep` the query heads this workgroup really serves, from head `q_head0`; the padding heads r >= nrep repeat the
+  // last real one (their logits / partials / outputs are never written out)
+  const int nrep = n_rep_real > 0 ? n_rep_real : REP;
+  const int hq0 = q_head0 >= 0 ? q_head0 : h * REP;
 
   uint4 qv[REP];
   float qf[REP][8];  // ROPE: rotated query q' (fp32)
 #pragma unroll
   for (int r = 0; r < REP; ++r) {
-    const __half* qp = a.q + ((size_t)ll * a.n_q_heads + h * REP + r) * D;
-    qv[r] = reinterpret_cast<const uint4*>(qp)[sub];
-    if (ROPE) {
+    const __half* qp = a.q + ((size_t)ll * a.n_q_heads + hq0 + min(r, nrep - 1)) * D;
+    qv[r] = live_lane ? reinterpret_cast<const uint4*>(qp)[sub] : uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qf[r][i] = 0.f;
+    if (ROPE && live_lane) {
       // q' = q*cos[T-1] + rotate_half(q)*sin[T-1]   (llama_patch.py:311, :326)
       const int half_d = D / 2;
       const float* c = a.rope_cos + (size_t)t_new * D;
@@ -83,35 +96,72 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   // RoPE-on-read: keys are cached un-rotated and rotated by their SLOT index j at read time (llama_patch.py:312, :327):
   // k'[d] = k[d]*cos[j][d] + rotate_half(k)[d]*sin[j][d]; the partner k[d +- D/2] sits in lane sub ^ LPR/2 of the row's lane
   // group.  The row is rotated ONCE (fp32) and then dotted with each of the REP rotated queries.
-  auto rope_key = [&](const uint4& kv, int j, float (&kp)[8]) {
+  //
+  // Where cos / sin come from (round 6).  A lane group walks KU CONSECUTIVE positions per iteration.  The tables are a rotation that is
+  // linear in the position — row j = (cos(j*theta_f), sin(j*theta_f)), include/easykv_hip.h — so only the FIRST row of an iteration
+  // is read from the table (the seed: exact table values) and the following KU - 1 rows advance the lane's 8 (cos, sin) pairs by the
+  // angle-addition recurrence with the step constants (cos theta_f, sin theta_f) = table row 1, held in registers: 4 flops per pair
+  // and step, a drift of a few fp32 roundings (< 1e-6 after 7 steps) before the next seed.  Before, every row loaded 64 B of fp32
+  // table per lane — 512 B of table per 256-B key row through the vector-memory path, and 16 table registers per row IN FLIGHT next
+  // to the K / V registers, which is what held the Llama-shape build at 4 rows in flight (25 of the 33 us over the plain stream:
+  // profiles/r05 mocks).  The sine is kept pre-multiplied by the half's sign (-1 for d < D/2): (c, s~) obeys the same recurrence with
+  // the step constant s~1, and the rotation is one fma + one multiply per element.  -DEKV_ROPE_EXACT=1 reads every row from the table.
+#ifndef EKV_ROPE_EXACT
+#define EKV_ROPE_EXACT 0
+#endif
+  const float sgn = (sub < LIVE / 2) ? -1.f : 1.f;
+  const int tab_off = (sub % (LIVE / 2)) * 8;      // cat(freqs, freqs): both halves of the lane group read the FIRST half of a row
+  auto rope_seed = [&](int j, ekv_f2 (&cc)[4], ekv_f2 (&ss)[4]) {
+#if EKV_ROPE_MOCK == 1      // (mock: no table loads — opaque constants, same arithmetic)
+    float one = 1.f, zero = 0.25f;
+    asm volatile("" : "+v"(one), "+v"(zero));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cc[i] = ekv_f2{one, one}, ss[i] = ekv_f2{zero, zero};
+    (void)j;
+#else
+    const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)j * D + tab_off);
+    const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)j * D + tab_off);
+    const float4 c0 = c4[0], c1 = c4[1], s0 = s4[0], s1 = s4[1];
+    cc[0] = ekv_f2{c0.x, c0.y}, cc[1] = ekv_f2{c0.z, c0.w}, cc[2] = ekv_f2{c1.x, c1.y}, cc[3] = ekv_f2{c1.z, c1.w};
+    ss[0] = ekv_f2{s0.x, s0.y} * sgn, ss[1] = ekv_f2{s0.z, s0.w} * sgn, ss[2] = ekv_f2{s1.x, s1.y} * sgn, ss[3] = ekv_f2{s1.z, s1.w} * sgn;
+#endif
+  };
+  ekv_f2 stp_c[4], stp_s[4];      // (cos theta_f, sgn * sin theta_f) of this lane's 8 frequencies
+  if (ROPE) rope_seed(min(1, a.n_slots - 1), stp_c, stp_s);
+  auto rope_advance = [&](ekv_f2 (&cc)[4], ekv_f2 (&ss)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const ekv_f2 cn = __builtin_elementwise_fma(cc[i], stp_c[i], -(ss[i] * stp_s[i]));
+      ss[i] = __builtin_elementwise_fma(ss[i], stp_c[i], cc[i] * stp_s[i]);
+      cc[i] = cn;
+    }
+  };
+  auto rope_rotate = [&](const uint4& kv, const ekv_f2 (&cc)[4], const ekv_f2 (&ss)[4], float (&kp)[8]) {
     uint4 other;
 #if EKV_ROPE_MOCK == 2      // (mock: no partner exchange)
     other = kv;
 #else
-    other.x = __shfl_xor(kv.x, LPR / 2, 64);
-    other.y = __shfl_xor(kv.y, LPR / 2, 64);
-    other.z = __shfl_xor(kv.z, LPR / 2, 64);
-    other.w = __shfl_xor(kv.w, LPR / 2, 64);
+    if (PADDED) {      // the partner piece d +- D/2 is LIVE/2 lanes away, not an xor pattern: ds_bpermute
+      const int src = (lane & ~(LPR - 1)) | (sub < LIVE / 2 ? sub + LIVE / 2 : (sub < LIVE ? sub - LIVE / 2 : sub));
+      other.x = __shfl(kv.x, src, 64);
+      other.y = __shfl(kv.y, src, 64);
+      other.z = __shfl(kv.z, src, 64);
+      other.w = __shfl(kv.w, src, 64);
+    } else {
+      other.x = __shfl_xor(kv.x, LPR / 2, 64);
+      other.y = __shfl_xor(kv.y, LPR / 2, 64);
+      other.z = __shfl_xor(kv.z, LPR / 2, 64);
+      other.w = __shfl_xor(kv.w, LPR / 2, 64);
+    }
 #endif
     const ekv_h8 kh = __builtin_bit_cast(ekv_h8, kv), oh = __builtin_bit_cast(ekv_h8, other);
-    // the tables are cat(freqs, freqs) (llama_patch.py:74-98; checked by KVBank.set_rope): both halves of the lane group read
-    // the FIRST half of the row, so a wave touches half as many table lines — the loop moved 4x more table than K bytes
-    // through the texture path (two fp32 tables against one fp16 row)
-    const float4* c4 = reinterpret_cast<const float4*>(a.rope_cos + (size_t)j * D + (sub % (LPR / 2)) * 8);
-    const float4* s4 = reinterpret_cast<const float4*>(a.rope_sin + (size_t)j * D + (sub % (LPR / 2)) * 8);
-#if EKV_ROPE_MOCK == 1      // (mock: no table loads — opaque constants, same arithmetic)
-    float one = 1.f, zero = 0.25f;
-    asm volatile("" : "+v"(one), "+v"(zero));
-    (void)c4; (void)s4;
-    const float4 c0 = make_float4(one, one, one, one), c1 = c0, s0 = make_float4(zero, zero, zero, zero), s1 = s0;
-#else
-    const float4 c0 = c4[0], c1 = c4[1], s0 = s4[0], s1 = s4[1];
-#endif
-    const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float sgn = (sub < LPR / 2) ? -1.f : 1.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) kp[i] = fmaf((float)kh[i], cc[i], sgn * (float)oh[i] * ss[i]);
+    for (int i = 0; i < 4; ++i) {
+      const ekv_f2 k2 = {(float)kh[2 * i], (float)kh[2 * i + 1]}, o2 = {(float)oh[2 * i], (float)oh[2 * i + 1]};
+      const ekv_f2 r2 = __builtin_elementwise_fma(k2, cc[i], o2 * ss[i]);
+      kp[2 * i] = r2[0];
+      kp[2 * i + 1] = r2[1];
+    }
   };
 
   const __half* k_new_row = a.k_new + ((size_t)ll * a.n_kv_heads + h) * D;
@@ -134,13 +184,20 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   auto appended_row = [&]() {
     if (!(has_new && wave == 0 && grp == 0)) return;
     const int slot_new = s_slot[t_new - slot_base];
-    const uint4 kn = reinterpret_cast<const uint4*>(k_new_row)[sub];
-    const uint4 vn = reinterpret_cast<const uint4*>(v_new_row)[sub];
+    uint4 kn = uint4{0, 0, 0, 0}, vn = uint4{0, 0, 0, 0};
     const size_t off = (head_row + slot_new) * D;          // append: the new row goes into the recycled slot
-    reinterpret_cast<uint4*>(a.k_w + off)[sub] = kn;
-    reinterpret_cast<uint4*>(a.v_w + off)[sub] = vn;
+    if (live_lane) {
+      kn = reinterpret_cast<const uint4*>(k_new_row)[sub];
+      vn = reinterpret_cast<const uint4*>(v_new_row)[sub];
+      reinterpret_cast<uint4*>(a.k_w + off)[sub] = kn;
+      reinterpret_cast<uint4*>(a.v_w + off)[sub] = vn;
+    }
     float kpn[8];
-    if (ROPE) rope_key(kn, t_new, kpn);
+    if (ROPE) {
+      ekv_f2 cn[4], sn[4];
+      rope_seed(t_new, cn, sn);
+      rope_rotate(kn, cn, sn, kpn);
+    }
 #pragma unroll
     for (int r = 0; r < REP; ++r) {
       float acc;
@@ -152,7 +209,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         acc = ekv_dot8(qv[r], kn, 0.f);
       }
       acc = ekv_group_sum<LPR>(acc) / a.sm_div;
-      if (logit_out != nullptr && sub == 0) logit_out[(size_t)r * logit_stride + (PHYS ? slot_new : t_new)] = acc;
+      if (logit_out != nullptr && sub == 0 && r < nrep) logit_out[(size_t)r * logit_stride + (PHYS ? slot_new : t_new)] = acc;
       // one more row for this lane group's online softmax
       const float mn = fmaxf(m[r], acc);
       const float alpha = m[r] == EKV_NEG_INF ? 0.f : exp2f((m[r] - mn) * EKV_LOG2E);
@@ -205,9 +262,15 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
       const __half* vp = a.v + (head_row + row) * D;
       // K/V rows are read exactly once per step and the cache (>1 GB) never fits L2/MALL: non-temporal loads
       // (measured on MI355X: 5.5 -> 6.1 TB/s on the pure stream)
-      kr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(kp) + sub));
-      vr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(vp) + sub));
+      if (live_lane) {
+        kr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(kp) + sub));
+        vr[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const ekv_u4*>(vp) + sub));
+      } else {
+        kr[u] = vr[u] = uint4{0, 0, 0, 0};
+      }
     }
+    ekv_f2 rc[4], rs[4];      // ROPE: (cos, signed sin) of row j0 for this lane's 8 frequencies — the seed, read with the K / V rows
+    if (ROPE) rope_seed(min(j0, t1 - 1), rc, rs);
     after_issue();
     // PHYS: bit u of dead8 = row j0+u is free / being appended / past the extent (j0 is a multiple of 8: one mask byte)
     const unsigned dead8 = PHYS ? (KU == 4 ? ((unsigned)s_dead[j0 >> 3] >> (j0 & 4)) & 0xFu : (unsigned)s_dead[j0 >> 3]) : 0u;
@@ -221,7 +284,11 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
         float kp[8];
-        rope_key(kr[u], min(j0 + u, t1 - 1), kp);
+        rope_rotate(kr[u], rc, rs, kp);
+        if (u + 1 < KU) {      // (cos, sin) of the next position
+          if (EKV_ROPE_EXACT) rope_seed(min(j0 + u + 1, t1 - 1), rc, rs);
+          else rope_advance(rc, rs);
+        }
 #pragma unroll
         for (int r = 0; r < REP; ++r) {
           float acc = 0.f;
@@ -254,7 +321,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         float mine = s[0];
 #pragma unroll
         for (int u = 1; u < KU; ++u) mine = (mu == u) ? s[u] : mine;
-        if (logit_out != nullptr && mu < KU && (PHYS ? !((dead8 >> mu) & 1u) : (j0 + mu < t1)))
+        if (logit_out != nullptr && mu < KU && r < nrep && (PHYS ? !((dead8 >> mu) & 1u) : (j0 + mu < t1)))
           logit_out[(size_t)r * logit_stride + j0 + mu] = mine;
       }
       float mx = s[0];
@@ -316,7 +383,7 @@ __device__ __forceinline__ void ekv_decode_stash(float* s_part, const float (&m)
   using Gm = EkvDecodeGeom<D, NW>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % Gm::LPR, grp = lane / Gm::LPR;
-  if (grp != 0) return;
+  if (grp != 0 || sub >= Gm::LIVE) return;
 #pragma unroll
   for (int r = 0; r < REP; ++r) {
     float* p = s_part + ((size_t)wave * REP + r) * Gm::PS;

@@ -133,9 +133,12 @@ template <int REP, int ITEMS, int NW = 4, bool PHYS = false>
 __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, int h, size_t head_row, int T, int off, int W,
                                                 float* s_logit, int t_pad, float* sS, float* sQ, float* sC, RedN<NW>& red,
                                                 uint32_t* s_hist, unsigned long long* s_list, int list_cap,
-                                                const float* part_max = nullptr, int n_part = 0, int part_stride = 0) {
+                                                const float* part_max = nullptr, int n_part = 0, int part_stride = 0, int nrep_in = 0) {
   const int tid = threadIdx.x;
   constexpr int NT = 64 * NW;
+  // GQA factors 3 / 5 / 6 / 7 run the REP = 4 / 8 build: the logit rows r >= nrep are copies of the last real head and stay out of
+  // the mean over the group (easykv/easykv.py:188-196 averages the rep real heads)
+  const int nrep = (REP == 1 || REP == 2 || nrep_in <= 0) ? REP : nrep_in;
   // cell[it] = physical row of position tid + it * NT, loaded once up front: PHYS reads the logits through it, and the
   // slot-map shift at the end writes straight from these registers (no dependent re-read + barrier at the very end)
   int cell[ITEMS];
@@ -228,8 +231,9 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
         if (j < W) {
           float pb = 0.f;
 #pragma unroll
-          for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + cell_off[it]] * inv_sm[r];
-          if (REP > 1) pb = pb / (float)REP;
+          for (int r = 0; r < REP; ++r)
+            if (r < nrep) pb += s_logit[(size_t)r * t_pad + cell_off[it]] * inv_sm[r];
+          if (REP > 1) pb = pb / (float)nrep;
           if (sc.policy == EKV_POLICY_TOVA) {
             sS[j] = pb;
           } else {
@@ -243,8 +247,9 @@ __device__ __forceinline__ void ekv_decode_tail(const EkvScoreArgs& sc, int ll, 
       for (int j = tid; j < W; j += NT) {
         float pb = 0.f;
 #pragma unroll
-        for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * t_pad + off + j] * inv_sm[r];
-        if (REP > 1) pb = pb / (float)REP;
+        for (int r = 0; r < REP; ++r)
+          if (r < nrep) pb += s_logit[(size_t)r * t_pad + off + j] * inv_sm[r];
+        if (REP > 1) pb = pb / (float)nrep;
         if (sc.policy == EKV_POLICY_TOVA) {
           sS[j] = pb;
         } else {
@@ -501,9 +506,10 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
                                                      const int32_t (&cB)[ITEMS], RedN<NW>& red, uint32_t* s_hist,
                                                      unsigned long long* s_list, int list_cap, const float* part_max, int n_part,
                                                      int part_stride, const uint32_t* s_deadw, int new_row, float g_old, float c_new,
-                                                     int nb) {
+                                                     int nb, int nrep_in = 0) {
   const int tid = threadIdx.x;
   constexpr int NT = 64 * NW;
+  const int nrep = (REP == 1 || REP == 2 || nrep_in <= 0) ? REP : nrep_in;      // (GQA factor 3 on the REP = 4 build: see ekv_decode_tail)
   const bool roco = sc.policy == EKV_POLICY_ROCO;
   const float g_new = g_old + sc.count_add;
   // this thread's rows: j = tid + it * NT; bit `it` of livem = the row holds a live entry (the appended row included)
@@ -549,8 +555,9 @@ __device__ __forceinline__ void ekv_decode_tail_slot(const EkvScoreArgs& sc, int
       if (lives(it)) {
         float pb = 0.f;
 #pragma unroll
-        for (int r = 0; r < REP; ++r) pb += s_logit[(size_t)r * l_pad + j] * inv_sm[r];
-        if (REP > 1) pb = pb / (float)REP;
+        for (int r = 0; r < REP; ++r)
+          if (r < nrep) pb += s_logit[(size_t)r * l_pad + j] * inv_sm[r];
+        if (REP > 1) pb = pb / (float)nrep;
         const bool fresh = j == new_row || sc.policy == EKV_POLICY_TOVA;
         const float s_new = fresh ? pb : sS[j] + pb;
         sS[j] = s_new;

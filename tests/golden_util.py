@@ -59,11 +59,33 @@ def trace_events(trace):
     return np.array(kinds, dtype=np.int8), ph, rg
 
 
+# What the output comparisons of a test session actually needed: written to gpurun_out/stable_fractions.txt by
+# tests/conftest.py when the session ends, quoted in DESIGN.md §4.
+OUT_STATS = dict(calls=0, elements=0, max_err=0.0, max_err_below_one=0.0, ulp_only=0, ulp_only_max_ref=0.0)
+
+
 def out_close(a, b, tol=1e-3):
-    """The north star's output bar: within 1e-3 of the reference on fp16 outputs — flat, rtol = 0.  The path's output dtype IS fp16
-    (as the reference's fp16 configurations'), so the rounding of the result itself is granted on top: |a - b| <= 1e-3 + half an
-    fp16 ulp of b (at |o| in [2, 4) half an ulp alone is 9.8e-4 — a bound on the UNROUNDED value no fp16 result can be held to)."""
+    """The north star's output bar: within 1e-3 of the reference on fp16 outputs — flat, rtol = 0.  Wherever the reference value is
+    below 1 in magnitude that is the whole test: |a - b| <= 1e-3, nothing granted.  The path's output dtype IS fp16 (as the reference's
+    fp16 configurations'), so for |b| >= 1 the rounding of the result itself is granted on top: |a - b| <= 1e-3 + half an fp16 ulp of b
+    (at |o| in [2, 4) half an ulp alone is 9.8e-4 — a bound on the UNROUNDED value no fp16 result can be held to).  How many elements
+    ever needed that allowance, and the plain max |a - b|, are counted in OUT_STATS."""
     import torch
     a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    err = (a - b).abs()
     half_ulp = torch.ldexp(torch.ones_like(b), torch.frexp(b)[1] - 12).clamp_min(2.0 ** -25)     # 0.5 * 2^(floor(log2|b|) - 10)
-    return bool(((a - b).abs() <= tol + half_ulp).all())
+    allow = torch.where(b.abs() < 1.0, torch.full_like(b, tol), tol + half_ulp)
+    ulp_only = (err > tol) & (err <= allow)
+    st = OUT_STATS
+    st["calls"] += 1
+    st["elements"] += err.numel()
+    if err.numel():
+        st["max_err"] = max(st["max_err"], float(err.max()))
+        below = err[b.abs() < 1.0]
+        if below.numel():
+            st["max_err_below_one"] = max(st["max_err_below_one"], float(below.max()))
+        n_ulp = int(ulp_only.sum())
+        if n_ulp:
+            st["ulp_only"] += n_ulp
+            st["ulp_only_max_ref"] = max(st["ulp_only_max_ref"], float(b.abs()[ulp_only].max()))
+    return bool((err <= allow).all())

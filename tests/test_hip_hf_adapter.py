@@ -178,6 +178,46 @@ def test_hipgraph_decode_step_equals_eager(mode, cfg, prompt):
     assert torch.equal(kv0[0], kv1[0]) and torch.equal(kv0[1], kv1[1])
 
 
+@pytest.mark.parametrize("mode,stride,cfg,prompt", [
+    ("encoding", 8, dict(budget=0.5, kv_policy="roco", max_new_tokens=6), 200),
+    ("encoding", 4, dict(budget=0.4, kv_policy="h2o_head", max_new_tokens=4, keep_attention=True), 150),
+    ("auto", 8, dict(budget=64, kv_policy="roco", max_new_tokens=24, recent_ratio=0.3), 240),
+    ("auto", 16, dict(budget=96, kv_policy="tova", max_new_tokens=8), 300),
+    ("ppl", 8, dict(budget=0.5, kv_policy="roco"), 200),
+    ("ppl", 8, dict(budget=0.5, kv_policy="recency", streaming=True), 160),
+])
+def test_hipgraph_chunk_forward_equals_eager(mode, stride, cfg, prompt):
+    """generation_config['hipgraph'] on the strided prefill (round 6): the steady-state chunk forward of the whole model — fixed
+    shapes, fixed plan, the cache returning to idx after every chunk (easykv/easykv.py:426-433) — replayed as one hipGraph must leave
+    the evicted ids of every forward, the retained slots, the score rows, the printed line and the result (text / perplexity) of the
+    eager loop."""
+    import easykv_amd
+    from easykv_amd import hf
+    model = hf.patch_model(_tiny(5))
+    easykv_amd.enable_fixed_kv(model, _Tok(), mode="encoding" if mode == "ppl" else mode, stride=stride)
+    ids = torch.randint(0, 97, (1, prompt), device="cuda")
+    runs = []
+    for use_graph in (False, True):
+        torch.manual_seed(11)
+        gen = model.easykv_ppl if mode == "ppl" else model.easykv_generate
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            out, cache = gen(input_ids=ids, generation_config=dict(cfg, eos_token_ids=[-1], temperature=0.7, hipgraph=use_graph,
+                                                                   _record_evictions=True), return_cache=True)
+        torch.cuda.synchronize()
+        b = cache.bank
+        t = cache.get_seq_length()
+        ev = [torch.stack(list(e)).cpu() for e in cache.evictions]
+        runs.append((out, buf.getvalue(), t, b.slot_of_pos[:, :, :t].clone(), b.score_sum[:, :, :t].clone(), b.ordered_kv(), ev))
+    (o0, l0, t0, s0, sc0, kv0, e0), (o1, l1, t1, s1, sc1, kv1, e1) = runs
+    assert l0 == l1 and t0 == t1
+    assert (abs(o0 - o1) <= 1e-6 * abs(o0)) if mode == "ppl" else (o0 == o1)
+    assert len(e0) == len(e1) and len(e0) >= 3, "the prompt must be long enough for several evicting chunks"
+    for a_, b_ in zip(e0, e1):
+        assert torch.equal(a_, b_)
+    assert torch.equal(s0, s1) and torch.equal(sc0, sc1)
+    assert torch.equal(kv0[0], kv1[0]) and torch.equal(kv0[1], kv1[1])
+
+
 @pytest.mark.parametrize("task, extra, expect", [
     ("decoding", ["--budgets", "40", "--max-new-tokens", "50"], ["EasyKV-roco(budget 40)"]),
     ("summarization", ["--max-new-tokens", "6"], ["KV cache budget ratio", "EasyKV-roco(50.00%)"]),
