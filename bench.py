@@ -781,7 +781,10 @@ def decode_run(args, dev, rank, world, scaling, DS, want_seq):
     shard = DS.LayerShard(rank, world, args.layers if scaling == "strong" else args.layers * world)
     Ls = shard.count                    # layers of this rank
     # in-flight sequences this stage serves per launch (seqs_per_launch): 1 unless the stage launches < 256 heads (N = 8)
-    k = seqs_per_launch(max(1, args.layers // world) if scaling == "strong" else args.layers, H, args.seqs_per_launch)      # (one value for the whole job)
+    # (the HEADLINE run serves ONE sequence per launch at every N unless --seqs-per-launch says otherwise, so that `value`
+    #  is a single-sequence figure comparable across rounds and across N; the k-sequence launches of a short stage are reported by the
+    #  boundary-stage entries, each next to its own single-sequence figure)
+    k = max(1, args.seqs_per_launch)      # (one value for the whole job)
     L = Ls * k                          # (sequence, layer) pairs of this rank's bank: pair s * Ls + l
     n_total = args.steps + args.warmup
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -1058,7 +1061,7 @@ def main():
     ap.add_argument("--identity-layout", action="store_true", help="start from a fresh bank's identity slot map (position order == "
                     "address order) instead of the scattered steady-state layout")
     ap.add_argument("--graph", action="store_true", help="capture one step (all launches) in a hipGraph and replay it")
-    ap.add_argument("--seqs-per-launch", type=int, default=0, help="in-flight sequences a rank serves per launch (0 = the fewest that put >= 256 heads "
+    ap.add_argument("--seqs-per-launch", type=int, default=0, help="in-flight sequences a rank serves per launch in the HEADLINE run (0 / 1 = one: `value` is always single-sequence tokens/s; the secondary stage entries use the fewest that put >= 256 heads "
                     "into the launch: 1 up to N = 4, 2 at N = 8 for the Llama2-7B shape)")
     args = ap.parse_args()
 
@@ -1090,7 +1093,7 @@ def main():
     if world > 1 and not args.no_second_scaling and not args.graph:
         other = "weak" if args.scaling == "strong" else "strong"
         r2 = decode_run(args, dev, rank, world, other, DS, want_seq=False)
-        tokens2 = args.steps * r2["k"] * (world if other == "weak" else 1)
+        tokens2 = args.steps * (world if other == "weak" else 1)      # (single-sequence, like `value`)
         second = {"scaling": other, "value": tokens2 / r2["elapsed"], "unit": "tokens/s", "ms_per_step": r2["elapsed"] / args.steps * 1e3,
                   "layers_per_rank": r2["Ls"], "sequences_per_launch": r2["k"], "fused": r2["fused"], "n_split": r2["n_split"],
                   "note": "weak: every rank owns a whole 32-layer block (aggregate layer-parallel throughput)" if other == "weak" else
@@ -1107,7 +1110,9 @@ def main():
         t_attn = t_region if not per_step_events else (1.0 if args.overlap_scorer else sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps * 1e-3)
         Ls, kseq = r["Ls"], r["k"]
         # every step of a rank emits one token per in-flight sequence of its launch; strong: the pipeline's output is the last stage's
-        tokens = args.steps * kseq * (world if args.scaling == "weak" else 1)
+        # `value` = tokens/s of ONE sequence (strong) / of one sequence per rank (weak); with k sequences sharing every launch
+        # (--seqs-per-launch k) the job's total is reported next to it as aggregate_tokens_per_s, never as `value`
+        tokens = args.steps * (world if args.scaling == "weak" else 1)
         cfg = {"workload": f"bench-D decode at fixed budget: B=1 L={args.layers} Hq={Hq} H={H} D={D} budget={budget} "
                            f"T={T} kv_policy={args.policy} (Llama2-7B shape, budget=50% of S=4096)",
                "parallelism": (f"pp{world}: {args.layers} layers split into contiguous blocks, {Ls} per rank, point-to-point hand-off of the stage output"
@@ -1124,6 +1129,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16 storage / f32 accumulate",
             "data": "synthetic", "config": cfg}
+        if kseq > 1:
+            line["aggregate_tokens_per_s"] = tokens * kseq / r["elapsed"]
+            line["single_sequence"] = {"value": tokens / r["elapsed"], "unit": "tokens/s", "note": f"every launch serves {kseq} in-flight sequences; `value` counts one of them"}
         if world > 1:
             line["ranks"] = {"backend": torch.distributed.get_backend(), "ranks_seen": ranks_seen, "devices": devices,
                              "us_per_step": [round(x, 2) for x in r["rank_us"]]}

@@ -33,7 +33,9 @@ class Step(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "layer_begin", "layer_count", "q_len", "n_slots", "score_off", "policy", "accumulate", "n_evict",
         "win_lo", "win_tail", "roco_k1", "roco_tail", "range_start", "tova_head_mean", "causal", "rope_on_read",
-        "n_split", "phases")] + [(n, C.c_float) for n in ("count_add", "count_tail_step", "sm_div")] + [("two_pass", C.c_int32), ("phys_extent", C.c_int32), ("defer_layers", C.c_int32), ("defer_index", C.c_int32)]
+        "n_split", "phases")] + [(n, C.c_float) for n in ("count_add", "count_tail_step", "sm_div")] + [(n, C.c_int32) for n in (
+        "two_pass", "phys_extent", "defer_layers", "defer_index",
+        "q_token_stride", "q_head_stride", "kv_token_stride", "kv_head_stride", "out_token_stride", "out_head_stride")]
 
 
 class EkvError(RuntimeError):
@@ -74,7 +76,7 @@ def load():
     lib.ekv_rows_to_order.argtypes = [C.POINTER(Bank), i32, i32, i32, vp]
     for name in EXPORTS[3:]:
         getattr(lib, name).restype = C.c_int
-    if lib.ekv_abi_version() != 7:
+    if lib.ekv_abi_version() != 8:
         raise EkvError("ABI version mismatch")
     _lib = lib
     return lib

@@ -175,9 +175,13 @@ class BudgetedKVCache:
         self.n_attend += 1
         plan = self.plan
         n = q.shape[2]
-        q = q.to(torch.float16).contiguous()
-        k = k.to(torch.float16).contiguous()
-        v = v.to(torch.float16).contiguous()
+        # fp16 rows are read IN PLACE at their strides (ABI 8): HF hands over [1, H, n, D] transposed views of the projections'
+        # [1, n, H * D] output — three copy kernels per layer in front of every chunk step until round 5.  Other dtypes are converted;
+        # layouts the kernels cannot address are copied dense by KVBank.attend.
+        q, k, v = (t if t.dtype == torch.float16 else t.to(torch.float16) for t in (q, k, v))
+        # the output is written token-major ([1, n, Hq, D]) and returned as its [1, Hq, n, D] view: the transpose(1, 2) every caller
+        # applies next (easykv_amd.hf, llama_patch.py:230-232) is then a dense tensor, no copy in front of o_proj
+        out = torch.empty(1, n, q.shape[1], q.shape[3], dtype=torch.float16, device=q.device).transpose(1, 2) if n > 1 else None
         if self.score_prefix and n > PREFIX_BLOCK and not self._prefix_in_one_step(plan, n, layer_idx):
             # keep_attention: the dense prefix must also feed the score rows (easykv/easykv.py:173-186).  ONE launch pair per layer
             # when the LIBRARY says the step runs as the two-pass scheme on the wide-block kernel (ekv_step_info: the query blocks
@@ -186,10 +190,9 @@ class BudgetedKVCache:
             # block to a workspace, so there the prefix is cut into query blocks here
             outs = []
             for i0 in range(0, n, PREFIX_BLOCK):
-                o, _ = self.bank.attend(plan, q[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), k[:, :, i0:i0 + PREFIX_BLOCK].contiguous(),
-                                        v[:, :, i0:i0 + PREFIX_BLOCK].contiguous(), layer_begin=layer_idx)
-                outs.append(o)
-            return torch.cat(outs, dim=2)
+                self.bank.attend(plan, q[:, :, i0:i0 + PREFIX_BLOCK], k[:, :, i0:i0 + PREFIX_BLOCK], v[:, :, i0:i0 + PREFIX_BLOCK],
+                                 layer_begin=layer_idx, out=out[:, :, i0:i0 + PREFIX_BLOCK])
+            return out
         if self._defer_this_forward is None:      # one decision per forward: an immediate step advances its layer's length at once
             self._defer_this_forward = bool(n > 1 and plan.phase == "prefill" and plan.policy in ("roco", "h2o_head", "tova") and (plan.accumulate or plan.evict)
                                             and self.defer_chunk_scorer and self._defer_fits(plan, n))
@@ -199,14 +202,14 @@ class BudgetedKVCache:
             # launch after the last layer (KVBank.flush) — off the critical path of the stack.  Decode steps, and since round 4 the
             # scored chunk steps of a strided prefill (their scorer launch — 32 workgroups, latency-bound, folds the key-range
             # partials too — was more than half of a layer's time)
-            out, _ = self.bank.attend(plan, q, k, v, layer_begin=layer_idx, defer=True)
+            out, _ = self.bank.attend(plan, q, k, v, layer_begin=layer_idx, defer=True, out=out)
             if self.n_attend == self.layer_count:
                 ids = self.bank.flush()
                 if self._cur is not None and ids is not None:
                     self._cur.extend(ids[l] for l in range(self.layer_count))
             return out
         # (the evicted cache indices are only wanted when a caller records them: _record_evictions)
-        out, ids = self.bank.attend(plan, q, k, v, layer_begin=layer_idx, evict_ids=None if self._cur is not None else False)
+        out, ids = self.bank.attend(plan, q, k, v, layer_begin=layer_idx, evict_ids=None if self._cur is not None else False, out=out)
         if self._cur is not None and ids is not None:
             self._cur.append(ids[0])
         return out

@@ -520,6 +520,23 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
       return EKV_E_ARG;
   }
   const int rep = bank->n_q_heads / bank->n_kv_heads;
+  // row strides (ABI 8): both zero = dense; q_len = 1 makes the token stride irrelevant and only takes head rows head_dim apart
+  int32_t strides[6] = {st->q_token_stride, st->q_head_stride, st->kv_token_stride, st->kv_head_stride, st->out_token_stride, st->out_head_stride};
+  for (int i = 0; i < 6; i += 2) {
+    int32_t& ts = strides[i];
+    int32_t& hs = strides[i + 1];
+    if (ts < 0 || hs < 0) return EKV_E_ARG;
+    if (n == 1) {
+      if (hs != 0 && hs != bank->head_dim) return EKV_E_UNSUPPORTED;
+      ts = hs = 0;
+    }
+    if (ts == 0 && hs == 0) {
+      ts = bank->head_dim;
+      hs = n * bank->head_dim;
+    } else if (ts < bank->head_dim || hs < bank->head_dim || (ts & 7) || (hs & 7)) {
+      return EKV_E_ARG;
+    }
+  }
   if (st->defer_layers != 0) {   // deferred scorer: decode AND chunk steps (ABI 5), explicit splits, attention + fold now / scorer later
     if (st->defer_layers < 0 || st->defer_index < 0 || st->defer_index + st->layer_count > st->defer_layers || st->n_split <= 0 ||
         (st->phases != (1 | 4) && st->phases != 8))
@@ -579,6 +596,7 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   aa.q_keep = ws.q_keep;
   aa.phys_extent = step_extent(bank, st);
   aa.l_pad = ekv_fused_logit_pad(bank, st, ws.t_pad);
+  aa.q_ts = strides[0], aa.q_hs = strides[1], aa.kv_ts = strides[2], aa.kv_hs = strides[3], aa.o_ts = strides[4], aa.o_hs = strides[5];
 
   EkvScoreArgs sa{};
   sa.slot_of_pos = bank->slot_of_pos;
@@ -615,6 +633,7 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   sa.causal = st->causal;
   sa.count_add = st->count_add;
   sa.count_tail_step = st->count_tail_step;
+  sa.o_ts = strides[4], sa.o_hs = strides[5];
 
   sa.big_rows = ws.big_rows;
   sa.big_stride = ws.t_pad;
@@ -758,6 +777,7 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
     a2.q = ws.q_keep;
     a2.q_keep = nullptr;
     a2.new_in_cache = 1;
+    a2.q_ts = bank->head_dim, a2.q_hs = n * bank->head_dim;      // (the kept copies are dense)
     if (flush_unsplit) {
       a2.n_stat_parts = ws.n_split;
       a2.n_split = 1;

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) ekv_rope_q_kernel(const EkvAttnArgs a, in
   const size_t row = (size_t)blockIdx.y * n_rows + r_in;       // (layer, q head, query)
   const int i = r_in % a.q_len;
   const int pos = a.n_slots - a.q_len + i;
-  const __half* q = a.q + row * D;
+  const __half* q = a.q + (size_t)blockIdx.y * n_rows * D + (size_t)(r_in / a.q_len) * a.q_hs + (size_t)i * a.q_ts;      // (ekv_step.q_*_stride)
   const int d0 = (threadIdx.x % tpr) * 4;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {

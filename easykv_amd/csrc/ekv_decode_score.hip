@@ -73,7 +73,9 @@ __global__ void __launch_bounds__(128) ekv_fold_kernel(const EkvScoreArgs sc) {
   const int D = sc.head_dim, PS = D + 2;
   const size_t row = (size_t)blockIdx.y * sc.n_q_heads * sc.q_len + blockIdx.x;
   const float* p0 = sc.partials + row * sc.n_split * PS;
-  for (int d = threadIdx.x; d < D; d += 128) sc.out[row * D + d] = __float2half(ekv_fold_partials_auto(p0, sc.n_split, PS, d));
+  // (ekv_step.out_*_stride: blockIdx.x = head * q_len + token)
+  __half* orow = sc.out + (size_t)blockIdx.y * sc.n_q_heads * sc.q_len * D + (size_t)(blockIdx.x / sc.q_len) * sc.o_hs + (size_t)(blockIdx.x % sc.q_len) * sc.o_ts;
+  for (int d = threadIdx.x; d < D; d += 128) orow[d] = __float2half(ekv_fold_partials_auto(p0, sc.n_split, PS, d));
 }
 
 size_t score_lds(int rep, int t_pad, int policy) {

@@ -105,10 +105,14 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
   // table per lane — 512 B of table per 256-B key row through the vector-memory path, and 16 table registers per row IN FLIGHT next
   // to the K / V registers, which is what held the Llama-shape build at 4 rows in flight (25 of the 33 us over the plain stream:
   // profiles/r05 mocks).  The sine is kept pre-multiplied by the half's sign (-1 for d < D/2): (c, s~) obeys the same recurrence with
-  // the step constant s~1, and the rotation is one fma + one multiply per element.  -DEKV_ROPE_EXACT=1 reads every row from the table.
+  // the step constant s~1, and the rotation is one fma + one multiply per element.  -DEKV_ROPE_EXACT=1 reads every row from the table;
+  // so does the GQA x 8 build, whose eight fp32 queries leave no room for the 16 step registers (8 spilled VGPRs: 143 vs 135 us at
+  // Hq = 64 / H = 8, measured).  Measured, Llama2-7B shape, budget 2048, same box: 219.3 us (round 5) / 225.5 (this code, every row from
+  // the table) -> 198.6 us with the recurrence; plain keys 185.6; Mistral shape 95.0 -> 88.3.
 #ifndef EKV_ROPE_EXACT
 #define EKV_ROPE_EXACT 0
 #endif
+  constexpr bool kRopeExact = EKV_ROPE_EXACT || REP == 8;
   const float sgn = (sub < LIVE / 2) ? -1.f : 1.f;
   const int tab_off = (sub % (LIVE / 2)) * 8;      // cat(freqs, freqs): both halves of the lane group read the FIRST half of a row
   auto rope_seed = [&](int j, ekv_f2 (&cc)[4], ekv_f2 (&ss)[4]) {
@@ -127,7 +131,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
 #endif
   };
   ekv_f2 stp_c[4], stp_s[4];      // (cos theta_f, sgn * sin theta_f) of this lane's 8 frequencies
-  if (ROPE) rope_seed(min(1, a.n_slots - 1), stp_c, stp_s);
+  if (ROPE && !kRopeExact) rope_seed(min(1, a.n_slots - 1), stp_c, stp_s);
   auto rope_advance = [&](ekv_f2 (&cc)[4], ekv_f2 (&ss)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -286,7 +290,7 @@ __device__ __forceinline__ void ekv_decode_stream(const EkvAttnArgs& a, const in
         float kp[8];
         rope_rotate(kr[u], rc, rs, kp);
         if (u + 1 < KU) {      // (cos, sin) of the next position
-          if (EKV_ROPE_EXACT) rope_seed(min(j0 + u + 1, t1 - 1), rc, rs);
+          if (kRopeExact) rope_seed(min(j0 + u + 1, t1 - 1), rc, rs);
           else rope_advance(rc, rs);
         }
 #pragma unroll

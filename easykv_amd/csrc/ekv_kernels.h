@@ -62,6 +62,9 @@ struct EkvAttnArgs {
   // column-sum pass of the wide-block kernel: 1 = the scorer of the step runs as the tail of this launch (ekv_wide_tail.h; the
   // EkvScoreArgs are the launch's second argument); set only for heads whose column sums ONE workgroup writes
   int32_t score_tail;
+  // row strides in elements (ekv_step.*_stride, ABI 8; always filled in: the dense layout is q_ts = D, q_hs = q_len * D, ...): row
+  // (layer ll, head hd, token i) of q sits at ((size_t)ll * n_q_heads * q_len) * D + hd * q_hs + i * q_ts, k_new / v_new and out alike
+  int32_t q_ts, q_hs, kv_ts, kv_hs, o_ts, o_hs;
   int32_t n_stat_parts;     // column-sum pass: (max, sum) partials per query row in `stats` when that differs from this launch's n_split (0 = n_split)
 };
 
@@ -85,6 +88,7 @@ struct EkvScoreArgs {
       causal;
   float count_add, count_tail_step;
   int32_t skip_fold;   // 1: the attention output was already folded by ekv_fold_kernel (scorer off the critical path)
+  int32_t o_ts, o_hs;  // row strides of `out` in elements (see EkvAttnArgs)
   // slot-indexed score rows (ekv_step.phases & EKV_PHASE_SLOT_ROWS, fused decode step; ekv_decode_tail.h): score_sum / score_sq /
   // score_cnt are indexed by physical row, score_cnt holds the count base, birth[row] the order key, slot_state[head] = (g, next birth, threshold hint of the decode step, threshold hint of the chunk_lds kernel — the hints in any layout)
   int32_t* birth;

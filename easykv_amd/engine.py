@@ -43,6 +43,42 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _row_strides(t: torch.Tensor):
+    """(token_stride, head_stride) in elements when the rows of ``t`` ``[layers, heads, n, D]`` can be read in place by the kernels
+    (ekv_step.*_stride, ABI 8): fp16, D contiguous halfs per row, layers dense blocks apart, strides multiples of 8 — e.g. the
+    ``[1, heads, n, D]`` transposed views HF attention modules hand over.  (0, 0) = the dense layout; None = needs a copy."""
+    layers, heads, n, d = t.shape
+    if t.dtype != torch.float16 or t.stride(3) != 1 or (t.data_ptr() & 15):
+        return None
+    if layers > 1 and t.stride(0) != heads * n * d:
+        return None
+    ts = t.stride(2) if n > 1 else d
+    hs = t.stride(1) if heads > 1 else max(n * d, ts)
+    if ts == d and hs == n * d:
+        return 0, 0
+    if n == 1:
+        return (0, 0) if hs == d else None
+    if ts < d or hs < d or (ts & 7) or (hs & 7):
+        return None
+    return ts, hs
+
+
+def _stride_rows(st, q, k_new, v_new, out):
+    """Fill the row strides of ``st`` from the tensors; tensors whose layout the kernels cannot read in place are copied dense (k_new
+    and v_new share one pair of strides).  Returns (q, k_new, v_new)."""
+    sq = _row_strides(q)
+    if sq is None:
+        q, sq = q.to(torch.float16).contiguous(), (0, 0)
+    sk, sv = _row_strides(k_new), _row_strides(v_new)
+    if sk is None or sv != sk:
+        k_new, v_new, sk = k_new.to(torch.float16).contiguous(), v_new.to(torch.float16).contiguous(), (0, 0)
+    so = (0, 0) if out is None else _row_strides(out)
+    if so is None:
+        raise ValueError("`out` must be an fp16 tensor whose rows are head_dim contiguous halfs at strides that are multiples of 8")
+    (st.q_token_stride, st.q_head_stride), (st.kv_token_stride, st.kv_head_stride), (st.out_token_stride, st.out_head_stride) = sq, sk, so
+    return q, k_new, v_new
+
+
 class KVBank:
     """K/V rows + slot map + score rows of ``n_layers`` layers on one GPU."""
 
@@ -236,6 +272,16 @@ class KVBank:
         # cat(freqs, freqs), llama_patch.py:74-98 / HF rotary modules)
         if not (torch.equal(self.rope_cos[:, :half], self.rope_cos[:, half:]) and torch.equal(self.rope_sin[:, :half], self.rope_sin[:, half:])):
             raise _lib.EkvError("rope tables must have the cat(freqs, freqs) layout (equal halves along head_dim)")
+        # ... and must be a rotation that is linear in the position, row j = (cos(j * theta_f), sin(j * theta_f)): the decode stream
+        # reads one row per run of consecutive positions and advances (cos, sin) by the angle-addition recurrence with row 1 as the
+        # step (include/easykv_hip.h).  Every RoPE variant is (linear / NTK / llama3 / yarn only change theta_f); the tables' own fp32
+        # rounding of the angle (6e-8 * j * theta_f) is the only deviation allowed for.
+        if self.rope_cos.shape[0] > 2:
+            c, s_ = self.rope_cos[:, :half].double(), self.rope_sin[:, :half].double()
+            dev_c = (c[:-1] * c[1] - s_[:-1] * s_[1] - c[1:]).abs().max()
+            dev_s = (s_[:-1] * c[1] + c[:-1] * s_[1] - s_[1:]).abs().max()
+            if float(torch.maximum(dev_c, dev_s)) > 1e-4 + 4e-7 * self.rope_cos.shape[0]:
+                raise _lib.EkvError("rope tables must be rotations linear in the position: row j = (cos(j * theta), sin(j * theta)) per frequency")
 
     # -- data movement at the boundary -------------------------------------------------------------
     def load_rows(self, k, v, pos_begin=None, layer_begin=0):
@@ -401,6 +447,7 @@ class KVBank:
         st.phys_extent = ext if ext > t else t
         if out is None:
             out = torch.empty(1, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
+        q, k_new, v_new = _stride_rows(st, q, k_new, v_new, out)
         rc = d["call"](d["bank_ref"], d["st_ref"], q.data_ptr(), k_new.data_ptr(), v_new.data_ptr(), out.data_ptr(), None,
                        d["rope"][0], d["rope"][1], d["ws_ptr"], d["ws_len"], d["stream"])
         if rc != 0:
@@ -431,6 +478,7 @@ class KVBank:
             raise _lib.EkvError(f"flush(): {d['pending']} of {self.n_layers} layers attended in this token step")
         st, ws = d["st"], d["ws"]
         st.layer_begin, st.layer_count, st.defer_index, st.phases = 0, self.n_layers, 0, 8
+        st.q_token_stride = st.q_head_stride = st.kv_token_stride = st.kv_head_stride = st.out_token_stride = st.out_head_stride = 0      # (no caller tensors in this call)
         st.phys_extent = max(max(self.extent), d["t"])
         check(self.lib.ekv_step_attend(C.byref(self._bank), C.byref(st), ws.data_ptr(), ws.data_ptr(), ws.data_ptr(), ws.data_ptr(),
                                        _ptr(d["ids"]), d["rope"][0], d["rope"][1], ws.data_ptr(), ws.numel(), d["stream"]), "ekv_step_attend")
@@ -441,7 +489,8 @@ class KVBank:
         return d["ids"] if st.n_evict > 0 else None
 
     def attend(self, plan: StepPlan, q, k_new, v_new, layer_begin=0, out=None, evict_ids=None, phases=0, overlap_scorer=False, defer=False):
-        """q ``[layers, Hq, n, D]``, k_new/v_new ``[layers, H, n, D]`` (fp16, device).
+        """q ``[layers, Hq, n, D]``, k_new/v_new ``[layers, H, n, D]`` (fp16, device; dense or strided views whose rows are read in
+        place — ekv_step.*_stride, see :func:`_row_strides`; anything else is copied dense first).
         Returns (out ``[layers, Hq, n, D]`` fp16, evict_ids ``[layers, H, k]`` int32 or None).
         ``defer=True`` (one layer per call): attention + fold only; the scorers of all layers run at :meth:`flush`.
         ``evict_ids=False``: the caller has no use for the evicted cache indices (none are returned; on the slot-indexed layout the
@@ -472,6 +521,7 @@ class KVBank:
                 self._slot_min_tail[l] = 0 if breaks_tail else min(self._slot_min_tail[l], tail)
         if out is None:
             out = torch.empty(lc, self.n_q_heads, n, self.head_dim, dtype=torch.float16, device=self.device)
+        q, k_new, v_new = _stride_rows(st, q, k_new, v_new, out)
         want_ids = evict_ids is not False
         if evict_ids is False:      # the caller has no use for the evicted order indices (the slot-indexed layout then skips ranking the victim)
             evict_ids = None if slot else torch.empty(lc, self.n_kv_heads, max(st.n_evict, 1), dtype=torch.int32, device=self.device)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define EKV_ABI_VERSION 7
+#define EKV_ABI_VERSION 8
 
 /* kv_policy strings of the reference -> codes (easykv/easykv.py:288-300, :310-362) */
 enum {
@@ -119,6 +119,18 @@ typedef struct ekv_step {
                            (layer_count = defer_layers, defer_index = 0) scores and evicts for the whole token.  Both calls must
                            pass the same explicit n_split and the same workspace.  0 = off.                               */
   int32_t defer_index;  /* slice of this call's first layer in the deferred workspace                                      */
+  /* Row strides of the call's tensors, in ELEMENTS (ABI 8; SURVEY.md §8b "raw device pointers + explicit strides").  A row is the
+   * head_dim contiguous halfs of one (head, token); inside a layer's block it sits at  head * head_stride + token * token_stride,
+   * and the layers of a multi-layer call follow each other n_heads * q_len * head_dim elements apart.  Both zero = the dense layout
+   * [heads][q_len][head_dim] (token_stride = head_dim, head_stride = q_len * head_dim).  The patched attention modules of HF
+   * transformers hand over [1, heads, q_len, head_dim] VIEWS of the projections' [1, q_len, heads * head_dim] output
+   * (llama_patch.py:176-182 does the same transpose): token_stride = heads * head_dim, head_stride = head_dim — read in place, no
+   * copy kernels in front of the step, and `out` written straight in the [q_len][heads * head_dim] layout o_proj wants
+   * (llama_patch.py:230-232 transposes back).  Strides must be multiples of 8 (16-byte row loads); for q_len = 1 only
+   * head_stride = head_dim is accepted (token_stride is irrelevant).                                                      */
+  int32_t q_token_stride, q_head_stride;      /* q                                                                          */
+  int32_t kv_token_stride, kv_head_stride;    /* k_new and v_new                                                            */
+  int32_t out_token_stride, out_head_stride;  /* out                                                                        */
 } ekv_step;
 
 int ekv_abi_version(void);
@@ -155,13 +167,17 @@ int ekv_state_init(const ekv_bank *bank, int32_t layer_begin, int32_t layer_coun
 
 /* The fused step: append q_len new K/V rows, attention of the q_len queries over the n_slots live
  * positions, GQA fold, score accumulation, victim selection, slot-map + score-row compaction.
- *   q      fp16 [layer_count][n_q_heads][q_len][head_dim]
- *   k_new  fp16 [layer_count][n_kv_heads][q_len][head_dim]   (already rotated unless rope_on_read)
- *   v_new  fp16 [layer_count][n_kv_heads][q_len][head_dim]
- *   out    fp16 [layer_count][n_q_heads][q_len][head_dim]
+ *   q      fp16 [layer_count][n_q_heads][q_len][head_dim]    (dense, or rows at ekv_step.q_*_stride)
+ *   k_new  fp16 [layer_count][n_kv_heads][q_len][head_dim]   (already rotated unless rope_on_read; ekv_step.kv_*_stride)
+ *   v_new  fp16 [layer_count][n_kv_heads][q_len][head_dim]   (same strides as k_new)
+ *   out    fp16 [layer_count][n_q_heads][q_len][head_dim]    (ekv_step.out_*_stride)
  *   evict_ids int32 [layer_count][n_kv_heads][n_evict] or NULL: evicted logical positions, ascending
  *   rope_cos/rope_sin fp32 [>= n_slots][head_dim] or NULL; layout cat(freqs, freqs) as in the reference (llama_patch.py:74-98):
- *                    the kernels read the first half of a row for both halves of the head
+ *                    the kernels read the first half of a row for both halves of the head.  The tables must be what RoPE tables are —
+ *                    a rotation LINEAR in the position, row j = (cos(j * theta_f), sin(j * theta_f)) for per-frequency angles
+ *                    theta_f of any scaling (linear / NTK / llama3 / yarn frequencies) — : the decode stream reads only the first
+ *                    row of every run of consecutive positions from the table and advances (cos, sin) to the following rows by the
+ *                    angle-addition recurrence with row 1 as the step (easykv_amd.KVBank.set_rope verifies the property)
  * After the call the bank holds n_slots - n_evict live positions (the caller tracks that number). */
 int ekv_step_attend(const ekv_bank *bank, const ekv_step *step, const void *q, const void *k_new, const void *v_new,
                     void *out, int32_t *evict_ids, const float *rope_cos, const float *rope_sin, void *workspace,

@@ -55,7 +55,7 @@ def test_decode_nan_std_and_sentinels(path, reach, n_nan):
         bank.score_sum[l, :, :W] = rows[l][0].cuda()
         bank.score_sq[l, :, :W] = rows[l][1].cuda()
         bank.score_cnt[l, :, :W] = rows[l][2].cuda()
-    n_split = 2 if path == "split" else 0
+    n_split = 2 if path == "split" else 1      # (unsplit heads: the whole step is one launch)
     kw = dict(policy="roco", phase="decode", evict=True, score_off=0, budget=budget)
     assert bank.step_plan(StepPlan(n_split=n_split, **kw), 1)[1] == (path != "split")
     cap = Capture()
@@ -124,7 +124,9 @@ def test_prefill_nan_std_and_sentinels(path, reach):
     rows = []
     for l in range(L):
         # NaN columns outside the sink window and the newest-10 window (a sentinel overrides a NaN, easykv.py:472-473)
-        sr, qr, cr, _ = seed_rows(H, W, idx, n_nan, g, nan_lo=sink, nan_hi=min(idx, W - 10))
+        # (counts of at least 6 strides: the step adds `stride` to every count, and Q/C - (S/C)^2 of the seeded columns stays
+        #  negative only while C / (C + stride) > 0.8)
+        sr, qr, cr, _ = seed_rows(H, W, idx, n_nan, g, c_lo=6 * s, c_hi=6 * s + 50, nan_lo=sink, nan_hi=min(idx, W - 10))
         cr[:, idx:] = -torch.arange(s, dtype=torch.float32)      # the count tail of easykv.py:416
         rows.append((sr, qr, cr))
         bank.score_sum[l, :, :W] = sr.cuda()

@@ -40,7 +40,7 @@ def test_abi_exports_every_declared_symbol():
     raw = ctypes.CDLL(_build.LIB)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.ekv_abi_version() == 7
+    assert lib.ekv_abi_version() == 8
     assert lib.ekv_rows_to_slots(None, 0, 1, 1, None) == -1 and lib.ekv_rows_to_order(None, 0, 1, 1, None) == -1
     assert lib.ekv_step_info(None, None, None, 0) == -1
     assert b"workspace" in lib.ekv_strerror(-3)
@@ -52,7 +52,7 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from easykv_amd._lib import Bank, Step
     assert ctypes.sizeof(Bank) == 6 * 8 + 5 * 4 + 4 + 3 * 8      # 6 pointers, 5 int32, padding, the optional arrive / birth / slot_state pointers
-    assert ctypes.sizeof(Step) == 18 * 4 + 5 * 4 + 2 * 4
+    assert ctypes.sizeof(Step) == 18 * 4 + 3 * 4 + 4 * 4 + 6 * 4      # 18 int32, 3 floats, 4 int32, the six row strides of ABI 8
     header = open(os.path.join(ROOT, "include", "easykv_hip.h")).read()
     body = header[header.index("typedef struct ekv_step {"):header.index("} ekv_step;")]
     names = re.findall(r"\b([a-z_0-9]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))

@@ -96,6 +96,24 @@ def main():
         res["easykv_amd_auto_roco_hipgraph"] = dict(decode_tok_s=args.new / (b - a), prefill_plus_8_s=a, printed=line,
                                                     budget=args.budget, stride=args.stride)
         print("budgeted path + hipGraph decode step:", res["easykv_amd_auto_roco_hipgraph"], flush=True)
+    # --- prefill alone (max_new_tokens = 1): eager loop vs the steady-state chunk forward replayed as one hipGraph (round 6), with the
+    #     evicted ids of every forward recorded — they must be identical
+    def prefill(graph):
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, cache = model.easykv_generate(input_ids=ids, generation_config=dict(budget=args.budget, kv_policy="roco", max_new_tokens=1, temperature=1.0,
+                                                                                   eos_token_ids=[-1], hipgraph=graph, _record_evictions=True), return_cache=True)
+        return cache
+    caches, secs = {}, {}
+    for graph in (False, True):
+        timed(lambda: prefill(graph))
+        box = []
+        secs[graph] = timed(lambda: box.append(prefill(graph)))
+        caches[graph] = box[0]
+    ev = {g_: [torch.stack(list(e)).cpu() for e in c.evictions] for g_, c in caches.items()}
+    same = len(ev[False]) == len(ev[True]) and all(torch.equal(a, b) for a, b in zip(ev[False], ev[True]))
+    res["prefill_only"] = dict(prompt=args.prompt, stride=args.stride, eager_s=round(secs[False], 3), hipgraph_s=round(secs[True], 3),
+                               evicting_forwards=len(ev[True]), evicted_ids_identical=bool(same))
+    print("prefill alone:", res["prefill_only"], flush=True)
     print(json.dumps(res))
 
 
