@@ -498,10 +498,22 @@ def generate(self, input_ids, generation_config, kv_mode="encoding", stride=1, r
         # prefix [0, r_idx): dense causal; with keep_attention its probabilities seed S and Q (:396, :403-405)
         plan = StepPlan(policy="roco" if keep_attention else "full", phase="prefill", accumulate=keep_attention,
                         evict=False, stride=stride)
-        out = forward(cache, input_ids[:, :r_idx], list(range(r_idx)), plan)
+        # extension key `dense_growth` (default off = the reference's forward sequence): the chunks that only GROW the cache —
+        # tokens [r_idx, idx): no eviction, and without keep_attention no accumulation either (easykv.py:443, :460) — attend
+        # causally to everything before them, which is what the dense prefix does: they join it as ONE forward of idx tokens.
+        # auto / ppl geometry takes the smallest r_idx (:551-552, :779-780), i.e. (idx - r_idx) / stride shape-changing forwards
+        # that no graph can replay (256 of the 511 forwards of a 4096-token prompt at stride 8).  Same K / V rows, same state, same
+        # evictions afterwards; with keep_attention the prefix' column sums are formed in one sweep instead of chunk by chunk
+        # (equal up to fp32 summation order).
+        r_dense = idx if cfg.get("dense_growth", False) else r_idx
+        out = forward(cache, input_ids[:, :r_dense], list(range(r_dense)), plan)
         cache.score_prefix = False
         logits_last = out.logits[:, -1, :]
         all_logits, all_ids = [], []
+        if keep_logits and r_dense > r_idx:      # (ppl mode collects the logits of every token from r_idx on, :816-901)
+            all_logits.append(out.logits[0, r_idx:r_dense])
+            all_ids.append(input_ids[0, r_idx:r_dense])
+        r_idx = r_dense
         cur_pos = r_idx
         graphed, prev_sig = None, None
         for tok_i in range(r_idx, length, stride):                # :426

@@ -193,3 +193,56 @@ def test_sampler_on_the_device_matches_reference_fixture():
             assert torch.allclose(got[r][both], ref[r][both], rtol=2e-5, atol=2e-6), (key, r, float((got[r][both] - ref[r][both]).abs().max()))
             assert int((got[r] > 0).sum()) >= 1
     assert n_bound > 2 * n_free, (n_bound, n_free)      # (free: the deep tail at top_p = 1.0 — running sum within 1e-5 of 1 — and the zeros of the greedy rows)
+
+
+def _growth_cases():
+    out = []
+    for n in _cases():
+        m = load_golden(n)["meta"]
+        if m["mode"] in ("encoding", "auto", "ppl") and m.get("rng_seed") is None and m.get("eos_token_ids", [-1]) == [-1]:
+            out.append(n)
+    return out
+
+
+@pytest.mark.parametrize("name", _growth_cases())
+def test_dense_growth_evicts_like_the_reference(name):
+    """generation_config['dense_growth'] (extension key, round 6): the chunks that only grow the cache — tokens [r_idx, idx), no
+    eviction, no count advance (easykv/easykv.py:443-461) — are attended as part of ONE dense prefix forward of idx tokens.  Against
+    the reference's own fixtures: the printed line, the result, every evicted id set, and every attention output (the prefix rows
+    against the reference's prefix + growth forwards, the evicting forwards one to one)."""
+    import easykv_amd
+    from easykv_amd.api import geometry
+    from tests.native_fake_model import NativeFakeModel
+    g = load_golden(name)
+    m = g["meta"]
+    cfg = dict(m["config"], eos_token_ids=[-1], _record_evictions=True, dense_growth=True)
+    budget = m["config"].get("budget", 0.5)
+    full = (m["mode"] == "ppl" and budget >= 1.0) or (m["mode"] == "encoding" and ((type(budget) == float and budget >= 1.0) or (type(budget) == int and budget >= m["length"])))
+    if full or (m["mode"] == "auto" and budget > m["length"]):
+        pytest.skip("no strided prefill in this fixture")
+    model = NativeFakeModel(*g["streams"], arch=m["arch"], vocab=m.get("vocab", 16))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res, cache = easykv_amd.generate(model, torch.arange(m["length"]).view(1, -1) % 16, cfg, kv_mode=m["mode"], stride=m["stride"], return_cache=True)
+    assert buf.getvalue().strip() == m["printed"]
+    if m["mode"] == "ppl":
+        assert abs(res - float(m["result"])) <= 1e-6 * float(m["result"])
+    else:
+        assert res == m["result"]
+    _, idx, r_idx = geometry("encoding" if m["mode"] == "encoding" else m["mode"], m["length"], budget, m["stride"])
+    n_growth = (idx - r_idx) // m["stride"]
+    ref_out = split_outputs(g)
+    assert len(model.outputs_log) == len(ref_out) - n_growth
+    prefix = model.outputs_log[0]
+    assert prefix.shape[2] == idx
+    assert out_close(prefix[:, :, :r_idx], ref_out[0], OUT_TOL)
+    for k in range(n_growth):
+        a = prefix[:, :, r_idx + k * m["stride"]:r_idx + (k + 1) * m["stride"]]
+        assert out_close(a, ref_out[1 + k], OUT_TOL), k
+    for f, (a, b) in enumerate(zip(model.outputs_log[1:], ref_out[1 + n_growth:])):
+        assert a.shape == b.shape and out_close(a, b, OUT_TOL), (f, float((a - b).abs().max()))
+    ours = [np.sort(torch.stack(e).cpu().numpy(), axis=-1) for e in cache.evictions]
+    ref = _ref_evictions(g, lambda i: ours[i].shape)
+    assert len(ours) == len(ref)
+    for step, (a, b) in enumerate(zip(ours, ref)):
+        assert np.array_equal(a, b), f"eviction ids differ at eviction {step}"
