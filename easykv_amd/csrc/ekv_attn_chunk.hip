@@ -19,7 +19,7 @@ EKW_DECL(64, 0) EKW_DECL(64, 2) EKW_DECL(128, 0) EKW_DECL(128, 2)
 // Two-pass scheme (16x16 kernel: statistics pass + exact pass with in-kernel column sums, ekv_attn_chunk.inc; wide-block kernel: one
 // pass for output + row statistics, then a K-only column-sum pass, ekv_attn_wide.inc) for scored chunk
 // steps.  It trades one extra read of K (and a third MFMA product) for the rep x n x T logits never touching HBM: at rep*n = 96
-// the logits are 384 B per key against 512 B of K + V, written once and read once.  Measured on MI355X: in
+// the logits are 384 B per key against 512 B of K + V, written once and read once.  Measured on MI355X (docs/TUNING.md §8): in
 // round 1 the one-pass path won at every BASELINE shape (C4 1.89 vs 2.31 ms); with the round-2 instruction diet of the MFMA
 // kernel the two passes win from ~40 query rows up (C4: 1.17 vs 1.48 ms per step, stride 64: 0.43 vs 0.49), so `auto` picks
 // them there.  Not with rope-on-read (every product is three MFMAs on the hi/lo pairs: C5 1.98 vs 2.59 ms).
@@ -54,7 +54,7 @@ void ekv_chunk_blocks(int rep, int q_len, int* qb_rows, int* n_qblocks, int* qpw
 }
 
 // Wide query blocks (33..128 GQA-folded rows) run on the 32x32x16 kernel of ekv_attn_wide.inc: the dense prefix and every wide
-// strided chunk step are bound by the MFMA kernel itself, not by HBM.  EKV_NO_WIDE=1 in the environment keeps
+// strided chunk step are bound by the MFMA kernel itself, not by HBM (docs/TUNING.md §3.5).  EKV_NO_WIDE=1 in the environment keeps
 // the 16x16x32 kernel (A/B measurements on one box).
 bool ekv_chunk_wide(int head_dim, int rep, int q_len, bool rope, bool two_pass, bool wants_logits) {
   static const bool off = [] { const char* e = std::getenv("EKV_NO_WIDE"); return e != nullptr && e[0] == '1'; }();

@@ -87,7 +87,7 @@ def event_overhead_us(dev, reps=32):
 
 def prewarm(step, seconds, dev):
     """Untimed pre-warm of a secondary figure: the same step for `seconds` of wall time.  A launch shape timed right after its first
-    use runs at lower clocks for hundreds of milliseconds (DESIGN.md §3.5 'a measurement trap': configs[3] 903 us per
+    use runs at lower clocks for hundreds of milliseconds (docs/TUNING.md §3.5 'a measurement trap': configs[3] 903 us per
     step behind 8
     warm-up steps, 857-863 us behind >= 25 ms of them) — the headline run has had --prewarm-s since round 1."""
     t_end = time.perf_counter() + seconds

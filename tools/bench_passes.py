@@ -1,6 +1,6 @@
 """Where does a wide chunk step's time go?  python tools/bench_passes.py [c3 s64 s96 c2 c4 l1]  (EASYKV_HIP_LIB=<variant .so> for A/B builds)
 Warmed: every figure is the mean of the LAST of 3 blocks, each block >= 0.3 s of the same launch — a configuration timed cold (first
-after process start) runs at lower clocks for hundreds of ms and once cost this repo a whole wrong kernel.
+after process start) runs at lower clocks for hundreds of ms and once cost this repo a whole wrong kernel (docs/TUNING.md §3.5).
  a) mode 0 alone (policy 'full')   b) attention launches of the scored step (phases=1)   c) whole step"""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

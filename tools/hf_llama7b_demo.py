@@ -84,7 +84,8 @@ def main():
     easykv_amd.enable_fixed_kv(model, Tok(), mode="auto", stride=args.stride)
 
     def run(n, record=False, **extra):
-        gc = dict(budget=args.budget, kv_policy="roco", max_new_tokens=n, temperature=1.0, eos_token_ids=[-1], eos_poll=16,
+        # (temperature 1e-6: the sampled tokens — and with them the evictions of the decode forwards — are the same in every run)
+        gc = dict(budget=args.budget, kv_policy="roco", max_new_tokens=n, temperature=1e-6, eos_token_ids=[-1], eos_poll=16,
                   _record_evictions=record, **extra)
         with contextlib.redirect_stdout(io.StringIO()) as buf:
             _, cache = model.easykv_generate(input_ids=ids, return_cache=True, generation_config=gc)

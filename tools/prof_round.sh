@@ -3,7 +3,7 @@
 # FETCH_SIZE / WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md: they do not fit one pass; never combined with a trace)
 # for the decode bench and for each strided-prefill shape.  Raw outputs -> gpurun_out/prof_$TAG; tools/summarize_prof.py
 # condenses them into profiles/${TAG}_*.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
