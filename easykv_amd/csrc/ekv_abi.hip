@@ -571,8 +571,9 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   aa.v_new = static_cast<const __half*>(v_new);
   aa.logits = ws.logits;
   aa.partials = ws.partials;
-  aa.rope_cos = st->rope_on_read ? rope_cos : nullptr;
-  aa.rope_sin = st->rope_on_read ? rope_sin : nullptr;
+  // (dry run: a non-null dummy — the dispatch reads "RoPE-on-read?" off this pointer, nothing is launched)
+  aa.rope_cos = st->rope_on_read ? (dry ? reinterpret_cast<const float*>(uintptr_t(256)) : rope_cos) : nullptr;
+  aa.rope_sin = st->rope_on_read ? (dry ? reinterpret_cast<const float*>(uintptr_t(256)) : rope_sin) : nullptr;
   aa.q_rot_hi = ws.q_rot;
   aa.q_rot_lo = ws.q_rot ? ws.q_rot + (size_t)st->layer_count * bank->n_q_heads * n * bank->head_dim : nullptr;
   aa.out_direct = ws.fold_in_kernel ? static_cast<__half*>(out) : nullptr;
@@ -670,7 +671,6 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // without the fold (4 and 8 let the caller run the scorer on a side stream, off the critical path)
   const int ph = st->phases;
   if (ph < 0 || ph > 15 || ((ph & 2) && (ph & (4 | 8)))) return EKV_E_ARG;
-  hipError_t err = hipSuccess;
   // Whole chunk step in ONE launch: unsplit heads (the kernel folds its own output), one-pass logits, a scored policy, and the
   // scorer's LDS rows fit next to two workgroups per CU.  The scorer of a head then runs as the tail of the workgroup that
   // streamed it and overlaps the K/V stream of the workgroups still running (tova_head_mean needs all heads of a layer first).
@@ -690,10 +690,14 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // The flush's column-sum launch covers ALL deferred layers: with >= 512 (head, layer, query-block group) units it runs UNSPLIT whatever
   // key-range split the one-layer calls of the one pass used (that split exists to fill the chip from 32 heads) — 1024 workgroups in one
   // resident round instead of 8192 short ones, and the scorer as its tail.
-  const bool flush_unsplit = flush_colsum && ws.wide && ws.two_pass && (size_t)st->layer_count * bank->n_kv_heads * ws.n_col_parts >= 512;
+  // (only where the tail can actually run on the unsplit pass — plain keys, a row the tail's registers hold, no scratch rows —;
+  //  a RoPE-on-read or W > 6144 flush keeps the one-layer calls' key-range split and their row bound, and the stand-alone scorer)
+  const bool tail_shape = n > 1 && ws.wide && ws.two_pass && ws.big_rows == nullptr && scored && st->accumulate &&
+                          st->policy != EKV_POLICY_TOVA && !st->rope_on_read;
+  const bool flush_unsplit = flush_colsum && tail_shape && ekv_wide_tail_supported(W, ws.n_col_parts) &&
+                             (size_t)st->layer_count * bank->n_kv_heads * ws.n_col_parts >= 512;
   const int tail_wgs = (flush_unsplit ? 1 : ws.n_split) * ws.n_col_parts;
-  const bool tail_step = n > 1 && ws.wide && ws.two_pass && (ph == 0 || flush_colsum) && ws.big_rows == nullptr && scored && st->accumulate &&
-                         st->policy != EKV_POLICY_TOVA && !st->rope_on_read && ekv_wide_tail_supported(W, tail_wgs);
+  const bool tail_step = tail_shape && (ph == 0 || flush_colsum) && ekv_wide_tail_supported(W, tail_wgs);
 
   // How the step ends, decided BEFORE anything is launched: a shape no scorer can take must be refused while the bank is
   // still untouched (the attention kernel appends the new rows).
@@ -712,63 +716,59 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // (GQA factors > 8 run several query-head groups per KV head, ekv_attn_decode.inc: the arrival counter counts one group's splits)
   const bool fold_in_decode = n == 1 && rep <= 8 && bank->arrive != nullptr && (ph == 0 || (ph & 1)) && !ws.fold_in_kernel &&
                               ((ph & 4) || (ph == 0 && (fold_only || range_only)));
-  if (plan_out) {      // kernel launches of this call (ekv_step_info): the same tests as the launch sequence below, in its order
-    int nl = 0;
-    if (ph == 0 || (ph & 1))
-      nl += n == 1 ? 1 : ((st->rope_on_read && !ws.wide ? 1 : 0) + (ws.two_pass ? (ws.q_keep != nullptr ? 1 : 2) : 1));
-    if (!(ph == 1 || fuse_chunk)) {
-      if (tail_step && ph == 0) {
-        nl += ws.fold_in_kernel ? 0 : 1;
-      } else {
-        if (((ph & 4) || fold_only || range_only) && (!(ph & 8) || (ph & 4)) && !ws.fold_in_kernel && !fold_in_decode) ++nl;
-        if (!fold_only) {
-          if (range_only) nl += st->n_evict > 0 ? 1 : 0;
-          else {
-            if (flush_colsum) ++nl;
-            if (!tail_step) nl += 1 + ((!fast_scorer && st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) ? 1 : 0);
-          }
-        }
-      }
-    }
-    plan_out->n_launches = nl;
-  }
-  if (dry) return EKV_OK;
+  // ---- the launch sequence.  ONE walk serves the real call and the dry run (ekv_step_check / ekv_step_plan / ekv_step_info): `go`
+  // counts a launch and, unless dry, issues it — so ekv_step_info's n_launches IS the sequence below, not a mirror of it.
+  int nl = 0;
+  auto done = [&](int rc) {
+    if (plan_out) plan_out->n_launches = rc == EKV_OK ? nl : 0;
+    return rc;
+  };
+  auto go = [&](int n_kernels, auto&& launch) -> bool {
+    nl += n_kernels;
+    return dry || launch() == hipSuccess;
+  };
+  auto chunk = [&](const EkvAttnArgs& A, bool two_pass, const EkvScoreArgs* fuse, int passes, const EkvScoreArgs* tail) -> bool {
+    return go(ekv_attn_chunk_launches(A, bank->head_dim, two_pass, passes),
+              [&] { return ekv_launch_attn_chunk(A, bank->head_dim, st->layer_count, two_pass, s, fuse, passes, tail); });
+  };
   if (fold_in_decode) {
     aa.arrive = bank->arrive + (size_t)st->layer_begin * bank->n_kv_heads;
     aa.out_direct = static_cast<__half*>(out);
   }
   if (ph != 0 && !(ph & 1)) {
   } else if (n == 1) {
-    err = ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s);
+    if (!go(1, [&] { return ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s); })) return done(EKV_E_LAUNCH);
   } else {
     if (tail_step && ph == 0) {
       // one pass (output / partials + row statistics) -> fold of the key-range partials, if any -> column-sum pass with the scorer as
       // its tail: two launches for an unsplit head
       sa.skip_fold = 1;
-      if (ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, true, s, nullptr, 1) != hipSuccess) return EKV_E_LAUNCH;
-      if (!ws.fold_in_kernel && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
-      return ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, true, s, nullptr, 2, &sa) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+      if (!chunk(aa, true, nullptr, 1, nullptr)) return done(EKV_E_LAUNCH);
+      if (!ws.fold_in_kernel && !go(1, [&] { return ekv_launch_fold(sa, st->layer_count, s); })) return done(EKV_E_LAUNCH);
+      return done(chunk(aa, true, nullptr, 2, &sa) ? EKV_OK : EKV_E_LAUNCH);
     }
     // (deferred wide two-pass step: only the one pass now — the column-sum pass runs with the scorer at the flush)
-    err = ekv_launch_attn_chunk(aa, bank->head_dim, st->layer_count, ws.two_pass != 0, s, fuse_chunk ? &sa : nullptr, ws.q_keep != nullptr ? 1 : 3);
+    if (!chunk(aa, ws.two_pass != 0, fuse_chunk ? &sa : nullptr, ws.q_keep != nullptr ? 1 : 3, nullptr)) return done(EKV_E_LAUNCH);
   }
-  if (err != hipSuccess) return EKV_E_LAUNCH;
-  if (ph == 1 || fuse_chunk) return EKV_OK;
+  if (ph == 1 || fuse_chunk) return done(EKV_OK);
 
   if ((ph & 4) || fold_only || range_only) {
     // (not even the fold when the attention kernel has already written the output)
     if (!(ph & 8) || (ph & 4)) {
-      if (!ws.fold_in_kernel && !fold_in_decode && ekv_launch_fold(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+      if (!ws.fold_in_kernel && !fold_in_decode && !go(1, [&] { return ekv_launch_fold(sa, st->layer_count, s); })) return done(EKV_E_LAUNCH);
     }
-    if (fold_only) return EKV_OK;
+    if (fold_only) return done(EKV_OK);
   }
   if (range_only) {
     if (st->n_evict > 0) {
-      hipLaunchKernelGGL(ekv_range_evict_kernel, dim3(bank->n_kv_heads, st->layer_count), dim3(256), (size_t)st->n_evict * 4, s,
-                         bank->slot_of_pos, evict_ids, bank->n_kv_heads, bank->cap, st->layer_begin, T, st->range_start, st->n_evict);
-      return launch_status();
+      const bool ok = go(1, [&] {
+        hipLaunchKernelGGL(ekv_range_evict_kernel, dim3(bank->n_kv_heads, st->layer_count), dim3(256), (size_t)st->n_evict * 4, s,
+                           bank->slot_of_pos, evict_ids, bank->n_kv_heads, bank->cap, st->layer_begin, T, st->range_start, st->n_evict);
+        return hipGetLastError();
+      });
+      return done(ok ? EKV_OK : EKV_E_LAUNCH);
     }
-    return EKV_OK;
+    return done(EKV_OK);
   }
   if (flush_colsum) {
     // the flush of a deferred chunk step: the column-sum pass of ALL layers (queries from the kept copies, the chunk's own rows from
@@ -783,17 +783,16 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
       a2.n_split = 1;
       a2.rows_per_split = ws.t_pad;
     }
-    if (ekv_launch_attn_chunk(a2, bank->head_dim, st->layer_count, true, s, nullptr, 2, tail_step ? &sa : nullptr) != hipSuccess) return EKV_E_LAUNCH;
-    if (tail_step) return EKV_OK;
+    if (!chunk(a2, true, nullptr, 2, tail_step ? &sa : nullptr)) return done(EKV_E_LAUNCH);
+    if (tail_step) return done(EKV_OK);
   }
   sa.skip_fold = ((ph & 8) || ws.fold_in_kernel) ? 1 : 0;
   if (fast_scorer)   // decode steps: the fast scorer (same tail as the fused kernel)
-    return ekv_launch_decode_score(sa, st->layer_count, s) == hipSuccess ? EKV_OK : EKV_E_LAUNCH;
+    return done(go(1, [&] { return ekv_launch_decode_score(sa, st->layer_count, s); }) ? EKV_OK : EKV_E_LAUNCH);
   if (st->policy == EKV_POLICY_TOVA && st->tova_head_mean && st->accumulate) {
-    if (ekv_launch_tova_headmean(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
+    if (!go(1, [&] { return ekv_launch_tova_headmean(sa, st->layer_count, s); })) return done(EKV_E_LAUNCH);
   }
-  if (ekv_launch_score_select(sa, st->layer_count, s) != hipSuccess) return EKV_E_LAUNCH;
-  return EKV_OK;
+  return done(go(1, [&] { return ekv_launch_score_select(sa, st->layer_count, s); }) ? EKV_OK : EKV_E_LAUNCH);
 }
 
 extern "C" {

@@ -111,6 +111,15 @@ bool ekv_wide_tail_supported(int W, int n_wg) {
   return !off && W >= 1 && W <= 24 * 256 && n_wg == 1;
 }
 
+// Kernel launches of ekv_launch_attn_chunk below for the same arguments: the query rotation of the 16x16 RoPE path, one launch per
+// pass of the wide kernel (`passes` bits), two for the 16x16 two-pass scheme.  Keep next to the launch code.
+int ekv_attn_chunk_launches(const EkvAttnArgs& a, int head_dim, bool two_pass, int passes) {
+  const bool rope = a.rope_cos != nullptr;
+  const bool wide = ekv_chunk_wide(head_dim, a.n_q_heads / a.n_kv_heads, a.q_len, rope, two_pass, a.logits != nullptr);
+  if (wide) return ((passes & 1) ? 1 : 0) + ((two_pass && (passes & 2)) ? 1 : 0);
+  return (rope ? 1 : 0) + (two_pass ? 2 : 1);
+}
+
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
                                  const EkvScoreArgs* fuse_sc, int passes, const EkvScoreArgs* tail_sc) {
   if (two_pass && fuse_sc != nullptr) return hipErrorInvalidValue;

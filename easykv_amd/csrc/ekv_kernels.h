@@ -104,6 +104,8 @@ hipError_t ekv_launch_attn_decode(const EkvAttnArgs& a, int head_dim, int layer_
 // tail_sc (wide-block kernel, two passes, passes & 2): the step's scorer runs as the tail of the column-sum pass (ekv_wide_tail.h)
 hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_count, bool two_pass, hipStream_t s,
                                  const EkvScoreArgs* fuse_sc = nullptr, int passes = 3, const EkvScoreArgs* tail_sc = nullptr);
+// kernel launches ekv_launch_attn_chunk issues for these arguments (the dry run's count; lives next to the launch code)
+int ekv_attn_chunk_launches(const EkvAttnArgs& a, int head_dim, bool two_pass, int passes);
 // can the scorer of a two-pass wide step run as the tail of its column-sum pass: W score columns, n_wg workgroups per head
 bool ekv_wide_tail_supported(int W, int n_wg);
 size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs& a);

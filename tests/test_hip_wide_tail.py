@@ -1,9 +1,10 @@
 """The scorer of a two-pass wide chunk step as the TAIL of the column-sum pass (easykv_amd/csrc/ekv_wide_tail.h, round 5) against
 the stand-alone scorer launch it replaces (``phases = 1`` then ``phases = 2``: the same attention launches, then
 ekv_score_select_kernel) on a twin bank: evicted ids, slot map and score rows must be EQUAL bit for bit — same column sums, same
-order of the sums, exact selects on both sides — over several consecutive steps (the tail's selects are warm-started from the
-head's previous thresholds), plain and RoPE-on-read keys, GQA, unsplit heads (the head's own workgroup scores it) and key-range
-splits / RoPE-on-read (which keep the stand-alone scorer: equal trivially, the launch count says which form ran).  The stand-alone scorer is pinned to the oracle / the reference's fixtures by
+order of the sums, exact selects on both sides — over several consecutive steps, plain and RoPE-on-read keys, GQA, unsplit heads
+(the head's own workgroup scores it) and key-range splits / RoPE-on-read (which keep the stand-alone scorer: equal trivially, the
+launch count says which form ran); and the flush of a deferred step whose column-sum pass runs UNSPLIT over all layers although
+the one-layer calls split their key ranges (the tail folds `n_stat_parts` row-statistics partials).  The stand-alone scorer is pinned to the oracle / the reference's fixtures by
 tests/test_hip_prefill_parity.py, tests/test_hip_fullsize_configs.py and tests/test_hip_wide_kernel.py.
 
 Reference: accumulate easykv/easykv.py:443-457, select :462-490, compaction :465-490 / :56-82."""
@@ -16,7 +17,7 @@ SHAPES = [
     # d, hq, h, n, t_prev, n_split, policy, streaming
     (128, 4, 4, 96, 1200, 1, "roco", False),        # configs[3]-shaped: 96 rows, unsplit
     (128, 4, 4, 96, 5002, 1, "roco", False),        # ... at its full width (W = 5098: 20 columns per thread)
-    (128, 4, 4, 96, 1200, 0, "roco", False),        # library-chosen splits (few heads: several workgroups per head, last arriver scores)
+    (128, 4, 4, 96, 1200, 0, "roco", False),        # library-chosen splits (few heads: several workgroups per head, stand-alone scorer)
     (128, 4, 4, 96, 2100, 4, "roco", False),
     (128, 8, 2, 16, 1232, 1, "h2o_head", False),    # configs[2]-shaped: Mistral GQA x4, 64 folded rows (2 x 2 waves)
     (128, 8, 2, 16, 1232, 2, "roco", False),
@@ -142,3 +143,52 @@ def test_launches_of_more_than_one_workgroup_per_cu_keep_the_four_wave_tiles():
             assert out_close(oa[4].float().cpu(), o_ref[0]), float((oa[4].float().cpu() - o_ref[0]).abs().max())
         assert torch.equal(oa, ob) and torch.equal(ia, ib), s
         assert torch.equal(a.slot_of_pos, b.slot_of_pos) and torch.equal(a.score_sum, b.score_sum) and torch.equal(a.score_cnt, b.score_cnt), s
+
+
+@pytest.mark.parametrize("streaming", [False, True], ids=["plain", "rope"])
+def test_deferred_flush_with_512_pairs_runs_unsplit_and_equals_the_whole_steps(streaming):
+    """a deferred flush over >= 512 (layer, head) pairs runs its column-sum pass UNSPLIT with the scorer as its tail while the
+    one-layer calls of the one pass used key-range splits (n_stat_parts != n_split: the pass folds the row-statistics partials of every
+    split) — plain keys only: a RoPE-on-read flush keeps the split and the stand-alone scorer.  Both forms must equal the immediate
+    per-layer steps bit for bit: outputs, evicted sets, slot maps, score rows."""
+    from easykv_amd import KVBank, StepPlan
+    from easykv_amd.api import rope_tables
+    L, hq, h, d, n, t0, steps = 16, 32, 32, 128, 96, 600, 2
+    g = torch.Generator().manual_seed(31 + int(streaming))
+    k0, v0 = torch.randn(L, h, t0, d, generator=g).half().cuda(), torch.randn(L, h, t0, d, generator=g).half().cuda()
+    qs = [torch.randn(L, hq, n, d, generator=g).half().cuda() for _ in range(steps)]
+    ks = [torch.randn(L, h, n, d, generator=g).half().cuda() for _ in range(steps)]
+    vs = [torch.randn(L, h, n, d, generator=g).half().cuda() for _ in range(steps)]
+    res = {}
+    for mode in ("whole", "deferred"):
+        bank = KVBank(L, hq, h, d, cap=t0 + n)
+        if streaming:
+            bank.set_rope(*rope_tables(bank.cap + 8, d))
+        bank.load_rows(k0, v0)
+        bank.state_init(t0 + n, 2, n)
+        outs, idl = [], []
+        for i in range(steps):
+            plan = StepPlan(policy="roco", phase="prefill", evict=True, accumulate=True, budget=t0 + n, recent=40, sink=4, stride=n,
+                            streaming=streaming, n_split=2, two_pass=1)
+            out = torch.empty(L, hq, n, d, dtype=torch.float16, device="cuda")
+            if mode == "whole":
+                ids = torch.full((L, h, n), -1, dtype=torch.int32, device="cuda")
+                for l in range(L):
+                    bank.attend(plan, qs[i][l:l + 1], ks[i][l:l + 1], vs[i][l:l + 1], layer_begin=l, out=out[l:l + 1], evict_ids=ids[l:l + 1])
+            else:
+                for l in range(L):
+                    bank.attend(plan, qs[i][l:l + 1], ks[i][l:l + 1], vs[i][l:l + 1], layer_begin=l, out=out[l:l + 1], defer=True)
+                if i == 0:      # the flush call's launches: column-sum pass (+ the stand-alone scorer unless it runs as the pass's tail)
+                    st = bank._defer["st"]
+                    st.layer_begin, st.layer_count, st.defer_index, st.phases = 0, L, 0, 8
+                    info = (__import__("ctypes").c_int32 * 9)()
+                    assert bank.lib.ekv_step_info(__import__("ctypes").byref(bank._bank), __import__("ctypes").byref(st), info, 9) == 0
+                    assert info[0] == 2 and info[8] == (2 if streaming else 1), list(info)
+                ids = bank.flush().clone()
+            outs.append(out)
+            idl.append(torch.sort(ids, dim=-1)[0])
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(outs), torch.stack(idl), bank.slot_of_pos[:, :, :t0].clone(), bank.score_sum[:, :, :t0].clone(),
+                     bank.score_sq[:, :, :t0].clone(), bank.score_cnt[:, :, :t0].clone())
+    for a, b in zip(res["whole"], res["deferred"]):
+        assert torch.equal(a, b)

@@ -183,7 +183,7 @@ def live_pmc(extra_args, kernel_substr, timeout_s=150, script=None):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ekv_pmc_", dir="/tmp")
         cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable]
-        cmd += ([script] if script else [os.path.abspath(__file__), "--no-cpu-baseline", "--steps", "16", "--warmup",
+        cmd += ([script] if script else [os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "16", "--warmup",
             "4", "--prewarm-s", "0.05",
                                          "--no-prefill", "--no-boundary", "--no-live-pmc"]) + extra_args
         try:

@@ -245,9 +245,13 @@ def prefill_pmc(S, stride, L, Hq, H, D, policy):
                    key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
     for f in reversed(files):
         try:
-            ks = json.load(open(f))[stem]["kernels"]
+            entry = json.load(open(f))[stem]
+            ks = entry["kernels"]
         except Exception:
             continue
+        # chunk steps the profiled child ran, as the child itself reports them (tools/bench_chunk.py "steps_run", round 6; ADVICE r5:
+        # counting them by kernel-name suffix double-counts run-time-rep instances and misses the RoPE logits instance)
+        steps_said = int((entry.get("bench_chunk_line") or {}).get("steps_run") or 0)
         one = [v for n,
             v in ks.items() if "ekv_chunk_lds_kernel" in n or ("ekv_attn_chunk_kernel" in n and "true>" in n)]
         if one:       # the whole step is one launch
@@ -257,8 +261,8 @@ def prefill_pmc(S, stride, L, Hq, H, D, policy):
         # steps of the profiled run = launches of the one pass (mode 0 instance `<.., 0>` of the wide-block kernel: once
         # per step); a
         # summary from before round 5 counts them by the scorer launches (every step had one)
-        steps = ([v["launches"] for n,
-            v in ks.items() if "ekv_attn_wide_kernel" in n and n.rstrip().endswith(", 0>")] or
+        steps = ([steps_said] if steps_said > 0 else
+                 [v["launches"] for n, v in ks.items() if "ekv_attn_wide_kernel" in n and n.rstrip().endswith(", 0>")] or
                  [v["launches"] for n, v in ks.items() if "ekv_score_select_kernel" in n])
         if two and steps:
             # launches per step from the launch counts: the two passes of the two-pass scheme may carry the same
