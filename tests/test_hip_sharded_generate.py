@@ -296,8 +296,10 @@ def test_bench_two_ranks_same_device_end_to_end(scaling):
 def test_bench_starts_its_own_ranks():
     """plain ``python bench.py --gpus 2`` (no launcher, no RANK / WORLD_SIZE in the environment) re-executes itself under
     torch.distributed.run and rank 0's line says ``n_gpus == 2`` — it used to run ONE rank silently.  (Both ranks on cuda:0 over gloo:
-    a gpurun box has one GPU; one rank per GPU over RCCL is the same path with the default backend.)  A 4-layer stage of the
-    Llama2-7B head shape launches two in-flight sequences per step (>= 256 heads: the one-launch decode step)."""
+    a gpurun box has one GPU; one rank per GPU over RCCL is the same path with the default backend.)  Round 6: `value` is
+    single-sequence tokens/s at every N — one sequence per launch by default; with ``--seqs-per-launch 2`` a 4-layer stage of the
+    Llama2-7B head shape serves two in-flight sequences per step (>= 256 heads: the one-launch decode step) and the job's total goes to
+    ``aggregate_tokens_per_s``, never into `value`."""
     import json
     import subprocess
     import sys
@@ -306,12 +308,20 @@ def test_bench_starts_its_own_ranks():
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "24", "--warmup", "4",
            "--prewarm-s", "0.05", "--layers", "8", "--budget", "256", "--no-prefill", "--no-second-scaling"]
-    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0
-    assert line["ranks"]["ranks_seen"] == 2 and len(line["ranks"]["us_per_step"]) == 2 and line["ranks"]["backend"] == "gloo"
-    assert line["config"]["layers_per_rank"] == 4 and line["config"]["sequences_per_launch"] == 2 and line["config"]["fused"] is True
-    assert abs(line["value"] - 2 * 24 / (line["ms_per_step"] * 24 * 1e-3)) < 1e-6 * line["value"]      # two tokens leave the pipeline per step
+    for k in (1, 2):
+        r = subprocess.run(cmd + (["--seqs-per-launch", "2"] if k == 2 else []), cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["value"] > 0
+        assert line["ranks"]["ranks_seen"] == 2 and len(line["ranks"]["us_per_step"]) == 2 and line["ranks"]["backend"] == "gloo"
+        assert line["config"]["layers_per_rank"] == 4 and line["config"]["sequences_per_launch"] == k
+        assert line["config"]["fused"] is (k == 2)       # 128 heads per launch: attention + scorer launches; 256: the one-launch step
+        assert abs(line["value"] - 24 / (line["ms_per_step"] * 24 * 1e-3)) < 1e-6 * line["value"]      # ONE sequence's tokens per second
+        if k == 2:
+            assert abs(line["aggregate_tokens_per_s"] - 2 * line["value"]) < 1e-6 * line["value"]
+            assert abs(line["single_sequence"]["value"] - line["value"]) < 1e-9 * line["value"]
+        else:
+            assert "aggregate_tokens_per_s" not in line

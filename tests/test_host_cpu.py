@@ -270,3 +270,23 @@ def test_step_info_launch_counts_of_the_baseline_shapes():
     dec = StepPlan(policy="roco", phase="decode", evict=True, score_off=0, budget=2048)
     assert (b.step_info(dec, 1)["fused"], b.step_info(dec, 1)["n_launches"]) == (1, 1)
     assert b.step_info(dec, 1, 0, 4)["n_launches"] == 2 and b.step_info(dec, 1, 0, 8)["fused"] == 1      # 128 heads: attention + scorer; 256: the 8-wave fused kernel
+    # round 6: launch counts come from the real launch sequence walked dry — phases, the deferred flush, GQA factors the builds pad
+    fl = bank(32, 32, 32, 128, 5098 + 63, 5002)
+    plan = StepPlan(policy="roco", phase="prefill", accumulate=True, evict=True, budget=5093, recent=509, sink=4, stride=96, n_split=4)
+    assert fl.step_info(plan, 96, 0, 1)["n_launches"] == 3                            # split heads: one pass + column-sum pass + scorer (which folds)
+    assert fl.step_info(plan, 96, 0, 1, phases=1 | 4)["n_launches"] == 3              # one pass + column-sum pass + fold
+    assert fl.step_info(plan, 96, 0, 1, phases=1)["n_launches"] == 2                  # attention launches only
+    assert fl.step_info(plan, 96, 0, 1, phases=2)["n_launches"] == 1                  # fold + scorer: the stand-alone scorer does both
+    assert fl.step_info(plan, 96, 0, 1, phases=8)["n_launches"] == 1
+    odd = bank(32, 24, 8, 128, 2049 + 63, 2048)                                        # GQA factor 3 (24 / 8 heads): the REP = 4 build
+    assert (odd.step_info(dec, 1)["fused"], odd.step_info(dec, 1)["n_launches"]) == (1, 1)
+    wide_gqa = bank(4, 48, 4, 128, 2049 + 63, 2048)                                    # GQA factor 12: query-head groups of 8, generic scorer
+    assert wide_gqa.step_info(dec, 1)["fused"] == 0 and wide_gqa.step_info(dec, 1)["n_launches"] == 2      # attention + the generic scorer (folds itself)
+    d96 = bank(32, 32, 32, 96, 2049 + 63, 2048)
+    assert d96.step_info(dec, 1)["fused"] == 1
+    # the unscored dense prefix runs 256-row query blocks (round 6); a scored one keeps 128
+    pre = bank(32, 32, 32, 128, 4906 + 63, 0)
+    info = pre.step_info(StepPlan(policy="full", phase="prefill", accumulate=False), 4906)
+    assert (info["wide"], info["qb_rows"], info["n_qblocks"], info["n_launches"]) == (1, 256, 20, 1), info
+    info = pre.step_info(StepPlan(policy="roco", phase="prefill", accumulate=True), 4906)
+    assert (info["wide"], info["two_pass"], info["qb_rows"]) == (1, 1, 128), info
