@@ -278,16 +278,6 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   const bool two_pass_plan = st->q_len > 1 && ekv_chunk_two_pass(bank->head_dim, rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass);
   const bool wide_plan = st->q_len > 1 && ekv_chunk_wide(bank->head_dim, rep, st->q_len, st->rope_on_read != 0, two_pass_plan,
                                                         !two_pass_plan && scored && st->accumulate != 0);
-  // The unscored dense prefix (and any other wide launch that only produces the attention output) of >= 512 folded rows runs 256-row
-  // query blocks: every K / V tile goes through L2 once per query block, so twice the rows per block is half the tile traffic of a
-  // launch that is bound by it (ekv_attn_wide.inc, shape 16; EKV_NO_BIG_BLOCK=1: A/B switch)
-  static const bool no_big_block = [] { const char* e = std::getenv("EKV_NO_BIG_BLOCK"); return e != nullptr && e[0] == '1'; }();
-  w.big_block = 0;
-  if (wide_plan && !two_pass_plan && !(scored && st->accumulate) && !st->rope_on_read && !no_big_block && rep * st->q_len >= 512 && 256 % rep == 0) {
-    w.big_block = 1;
-    w.qb_rows = 256 / rep;
-    w.n_qblocks = (st->q_len + w.qb_rows - 1) / w.qb_rows;
-  }
   if (n_split <= 0 && st->q_len > 1) {
     // Chunk steps (two or three workgroups per CU): a split costs a partial per query row and split, a fold in the scorer and a
     // shorter stream per workgroup, so the grid is filled to the 256..512 workgroups that are resident at a time — not to 1024:
@@ -603,7 +593,6 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   aa.causal = st->causal;
   aa.qb_rows = ws.qb_rows;
   aa.n_qblocks = ws.n_qblocks;
-  aa.big_block = ws.big_block;
   aa.sm_div = st->sm_div;
   aa.q_keep = ws.q_keep;
   aa.phys_extent = step_extent(bank, st);

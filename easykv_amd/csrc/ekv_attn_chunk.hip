@@ -126,11 +126,6 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
   if (tail_sc != nullptr && !(two_pass && (passes & 2))) return hipErrorInvalidValue;
   int qb_rows, n_qblocks, qpw;
   ekv_chunk_blocks(a.n_q_heads / a.n_kv_heads, a.q_len, &qb_rows, &n_qblocks, &qpw);
-  if (a.big_block) {      // 256-row query blocks (ekv_plan_workspace decides; unscored wide launches only)
-    qb_rows = 256 / (a.n_q_heads / a.n_kv_heads);
-    n_qblocks = (a.q_len + qb_rows - 1) / qb_rows;
-    if (two_pass || a.logits != nullptr || a.rope_cos != nullptr) return hipErrorInvalidValue;
-  }
   if (qb_rows != a.qb_rows || n_qblocks != a.n_qblocks) return hipErrorInvalidValue;
   const bool rope = a.rope_cos != nullptr;
   const bool wide = ekv_chunk_wide(head_dim, a.n_q_heads / a.n_kv_heads, a.q_len, rope, two_pass, a.logits != nullptr);
@@ -153,17 +148,13 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
       // (... and key ranges long enough to hold several 128-key tiles: measured per one-layer call, 64-key / 128-key tiles — 96 rows x 640 keys
       //  per split 43.2 / 38.2 us; 64 rows x 272 keys 24.5 / 26.1; 32 layers x 8 KV heads x 1248 keys unsplit (configs[2]) 43.1 / 41.5)
       const bool small = (size_t)layer_count * a.n_kv_heads * a.n_split * a.n_qblocks <= 256 && a.rows_per_split >= 512;
-      const int shape0 = a.big_block ? 16 : ((!rope && small && !no_big) ? (nwq == 4 ? 8 : 9) : nwq);      // workgroup-shape code of ekv_attn_wide.inc's entry (8 / 9: 128-key tiles; 16: 256-row blocks)
+      const int shape0 = (!rope && small && !no_big) ? (nwq == 4 ? 8 : 9) : nwq;      // workgroup-shape code of ekv_attn_wide.inc's entry (8 / 9: 128-key tiles)
       e = head_dim == 128 ? EKW_GO(128, 0, a, shape0, nullptr) : EKW_GO(64, 0, a, shape0, nullptr);
     }
     if (two_pass && (passes & 2) && e == hipSuccess) {
       EkvAttnArgs a2 = a;
       a2.score_tail = tail_sc != nullptr ? 1 : 0;
-      // (a launch of at most one workgroup per CU over long key ranges: 128-key tiles, see ekv_attn_wide.inc's entry; EKV_NO_BIG_TILE2=1: A/B)
-      static const bool no_big2 = [] { const char* ev = std::getenv("EKV_NO_BIG_TILE2"); return ev != nullptr && ev[0] == '1'; }();
-      const bool small2 = (size_t)layer_count * a.n_kv_heads * a.n_split * a.n_col_parts <= 256 && a.rows_per_split >= 512;
-      const int shape2 = (!rope && small2 && !no_big2) ? (nwq == 4 ? 8 : 9) : nwq;
-      e = head_dim == 128 ? EKW_GO(128, 2, a2, shape2, tail_sc) : EKW_GO(64, 2, a2, shape2, tail_sc);
+      e = head_dim == 128 ? EKW_GO(128, 2, a2, nwq, tail_sc) : EKW_GO(64, 2, a2, nwq, tail_sc);
     }
 #undef EKW_GO
     return e;

@@ -24,7 +24,6 @@ struct EkvWs {
   int32_t t_pad, n_split, rows_per_split;
   int32_t n_partials;   // partials per query row the scorer folds (chunk kernels emit 2 per split)
   int32_t qb_rows, n_qblocks;
-  int32_t big_block;    // 256-row query blocks (unscored wide launches of >= 512 folded rows: the dense prefix)
   size_t bytes;
 };
 
@@ -50,7 +49,6 @@ struct EkvAttnArgs {
   int32_t n_col_parts;   // = query-tile waves per workgroup (2 or 4) * n_qblocks
   int32_t n_q_heads, n_kv_heads, cap, n_slots, q_len, n_split, rows_per_split, t_pad, layer_begin, causal;
   int32_t qb_rows, n_qblocks;  // chunk kernels: queries per query block, number of query blocks
-  int32_t big_block;           // wide-block kernel: 256-row query blocks on eight query waves (qb_rows = 256 / rep)
   int32_t phys_extent;         // fused decode step, physical-order stream: live rows have physical index < phys_extent
   int32_t l_pad;               // fused decode step: pitch of a logits row in LDS (t_pad, or align(phys_extent, 64))
   uint32_t* arrive;            // split decode kernel: non-null = fold the key-range partials in the kernel (last-arriving split of a

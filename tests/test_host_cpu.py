@@ -284,9 +284,9 @@ def test_step_info_launch_counts_of_the_baseline_shapes():
     assert wide_gqa.step_info(dec, 1)["fused"] == 0 and wide_gqa.step_info(dec, 1)["n_launches"] == 2      # attention + the generic scorer (folds itself)
     d96 = bank(32, 32, 32, 96, 2049 + 63, 2048)
     assert d96.step_info(dec, 1)["fused"] == 1
-    # the unscored dense prefix runs 256-row query blocks (round 6); a scored one keeps 128
+    # the dense prefix: 128-row query blocks walked inside one launch (unscored) / one pass + column-sum pass with the tail (scored)
     pre = bank(32, 32, 32, 128, 4906 + 63, 0)
     info = pre.step_info(StepPlan(policy="full", phase="prefill", accumulate=False), 4906)
-    assert (info["wide"], info["qb_rows"], info["n_qblocks"], info["n_launches"]) == (1, 256, 20, 1), info
+    assert (info["wide"], info["qb_rows"], info["n_qblocks"], info["n_launches"]) == (1, 128, 39, 1), info
     info = pre.step_info(StepPlan(policy="roco", phase="prefill", accumulate=True), 4906)
-    assert (info["wide"], info["two_pass"], info["qb_rows"]) == (1, 1, 128), info
+    assert (info["wide"], info["two_pass"], info["qb_rows"], info["n_launches"]) == (1, 1, 128, 2), info
