@@ -234,13 +234,16 @@ def test_random_long_decode_runs(seed):
     assert bank.n_slots == [T0] * L
 
 
-@pytest.mark.parametrize("policy,D,rep", [("roco", 128, 1), ("roco", 64, 2), ("h2o_head", 32, 4)])
-def test_long_run_steady_state_decode_against_the_oracle(policy, D, rep):
+@pytest.mark.parametrize("policy,D,rep,stream", [("roco", 128, 1, False), ("roco", 64, 2, False), ("h2o_head", 32, 4, False),
+                                                  ("roco", 128, 1, True), ("roco", 96, 3, True)])
+def test_long_run_steady_state_decode_against_the_oracle(policy, D, rep, stream):
     """1200 evicting decode steps at a small fixed budget through the ONE-LAUNCH decode step (physical-order stream, histogram
     select): long enough for the policy's steady state, where the lowest-mean tokens are exactly the ones outside roco's
     feasible set and the slot map is a random permutation.  The oracle is re-seeded from the bank's own state before every
     step (ordered K/V, score rows), so each of the 1200 x 8 decisions is checked on its own — a trajectory followed freely
-    is lost at its first unstable draw, after ~100 steps.  Every decision the probe calls well defined must match."""
+    is lost at its first unstable draw, after ~100 steps.  Every decision the probe calls well defined must match.  The streaming
+    cases (round 6) run RoPE-on-read with cos / sin advanced by recurrence between table seeds (ekv_decode_stream.h) against the
+    oracle's table lookups — incl. head_dim 96 with GQA factor 3."""
     from easykv_amd import KVBank, StepPlan
     from oracle import easykv_oracle as O
     L, H, budget, steps = 2, 4, 120, 1200
@@ -248,9 +251,13 @@ def test_long_run_steady_state_decode_against_the_oracle(policy, D, rep):
     g = torch.Generator().manual_seed(77 + D)
     k0, v0 = _mk(L, H, budget, D, g), _mk(L, H, budget, D, g)
     bank = KVBank(L, Hq, H, D, cap=budget + 9)
+    cos = sin = None
+    if stream:
+        cos, sin = O.rope_tables(budget + 80, D)
+        bank.set_rope(cos, sin)
     bank.load_rows(k0.cuda(), v0.cuda())
     bank.state_init(W, 0)
-    kw = dict(policy=policy, phase="decode", evict=True, score_off=0, budget=budget)
+    kw = dict(policy=policy, phase="decode", evict=True, score_off=0, budget=budget, streaming=stream)
     assert bank.step_plan(StepPlan(n_split=1, **kw), 1) == (1, True)
     verified = unstable = 0
     probe = Probe()
@@ -263,11 +270,11 @@ def test_long_run_steady_state_decode_against_the_oracle(policy, D, rep):
             out, ids = bank.attend(StepPlan(n_split=1, **kw), q.cuda(), k.cuda(), v.cuda())
             for l in range(L):
                 st = O.LayerState(k=kord[l:l + 1], v=vord[l:l + 1], s=rows[0][l], q=rows[1][l], c=rows[2][l])
-                o_ref, ids_ref = O.layer_step(st, q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw))
+                o_ref, ids_ref = O.layer_step(st, q[l:l + 1].float(), k[l:l + 1].float(), v[l:l + 1].float(), O.StepPlan(**kw), cos, sin)
                 assert out_close(out[l].float().cpu(), o_ref[0]), (i, l)
                 same = ids[l, :, 0].cpu().long() == ids_ref[:, 0]
                 ok = ~probe.last_unstable
-                assert bool(same[ok].all()), (i, l, policy, D, rep)
+                assert bool(same[ok].all()), (i, l, policy, D, rep, stream)
                 verified += int(ok.sum())
                 unstable += int((~ok).sum())
     finally:
