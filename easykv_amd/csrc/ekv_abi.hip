@@ -690,11 +690,14 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   // The flush's column-sum launch covers ALL deferred layers: with >= 512 (head, layer, query-block group) units it runs UNSPLIT whatever
   // key-range split the one-layer calls of the one pass used (that split exists to fill the chip from 32 heads) — 1024 workgroups in one
   // resident round instead of 8192 short ones, and the scorer as its tail.
-  // (only where the tail can actually run on the unsplit pass — plain keys, a row the tail's registers hold, no scratch rows —;
-  //  a RoPE-on-read or W > 6144 flush keeps the one-layer calls' key-range split and their row bound, and the stand-alone scorer)
+  // ADVICE r5 asked for this branch to be tied to the tail or measured on its own.  Measured (round 6, one layer per call, flush over 40
+  // layers x 40 heads, configs[4] shape with RoPE-on-read, where the tail does NOT run): unsplit flush 92.4-93.0 us per layer against
+  // 94.1-94.8 us with the one-layer calls' key-range split kept — so a flush runs unsplit WHENEVER the key range fits what an unsplit
+  // workgroup may walk (the row bound ekv_plan_workspace applies to n_split: slot entries of the range live in LDS — 6144 rows with
+  // RoPE-on-read, 16384 plain), tail or not; beyond that bound it keeps the split.
   const bool tail_shape = n > 1 && ws.wide && ws.two_pass && ws.big_rows == nullptr && scored && st->accumulate &&
                           st->policy != EKV_POLICY_TOVA && !st->rope_on_read;
-  const bool flush_unsplit = flush_colsum && tail_shape && ekv_wide_tail_supported(W, ws.n_col_parts) &&
+  const bool flush_unsplit = flush_colsum && ws.wide && ws.two_pass && T <= (st->rope_on_read ? 6144 : 16384) &&
                              (size_t)st->layer_count * bank->n_kv_heads * ws.n_col_parts >= 512;
   const int tail_wgs = (flush_unsplit ? 1 : ws.n_split) * ws.n_col_parts;
   const bool tail_step = tail_shape && (ph == 0 || flush_colsum) && ekv_wide_tail_supported(W, tail_wgs);

@@ -48,12 +48,13 @@ def _row_strides(t: torch.Tensor):
     (ekv_step.*_stride, ABI 8): fp16, D contiguous halfs per row, layers dense blocks apart, strides multiples of 8 — e.g. the
     ``[1, heads, n, D]`` transposed views HF attention modules hand over.  (0, 0) = the dense layout; None = needs a copy."""
     layers, heads, n, d = t.shape
-    if t.dtype != torch.float16 or t.stride(3) != 1 or (t.data_ptr() & 15):
+    s0, s1, s2, s3 = t.stride()
+    if t.dtype != torch.float16 or s3 != 1 or (t.data_ptr() & 15):
         return None
-    if layers > 1 and t.stride(0) != heads * n * d:
+    if layers > 1 and s0 != heads * n * d:
         return None
-    ts = t.stride(2) if n > 1 else d
-    hs = t.stride(1) if heads > 1 else max(n * d, ts)
+    ts = s2 if n > 1 else d
+    hs = s1 if heads > 1 else max(n * d, ts)
     if ts == d and hs == n * d:
         return 0, 0
     if n == 1:
@@ -66,6 +67,14 @@ def _row_strides(t: torch.Tensor):
 def _stride_rows(st, q, k_new, v_new, out):
     """Fill the row strides of ``st`` from the tensors; tensors whose layout the kernels cannot read in place are copied dense (k_new
     and v_new share one pair of strides).  Returns (q, k_new, v_new)."""
+    f16 = torch.float16
+    if (q.dtype is f16 and k_new.dtype is f16 and v_new.dtype is f16 and q.is_contiguous() and k_new.is_contiguous() and v_new.is_contiguous()
+            and (out is None or out.is_contiguous())):
+        # dense tensors (the bank-level callers: tests, bench): a few C++ calls — this sits on the per-layer critical path of a decoder
+        # stack, where the host cost of a call is what bounds small layers
+        if st.q_token_stride or st.q_head_stride or st.kv_token_stride or st.kv_head_stride or st.out_token_stride or st.out_head_stride:
+            st.q_token_stride = st.q_head_stride = st.kv_token_stride = st.kv_head_stride = st.out_token_stride = st.out_head_stride = 0
+        return q, k_new, v_new
     sq = _row_strides(q)
     if sq is None:
         q, sq = q.to(torch.float16).contiguous(), (0, 0)
