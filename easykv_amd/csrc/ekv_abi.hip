@@ -275,9 +275,19 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
       ekv_decode_fused_supported(bank->head_dim, rep, T, w.t_pad, ekv_fused_logit_pad(bank, st, w.t_pad), st->n_evict, bank->cap, 8)) {
     n_split = 1;   // >= 1 head per CU: one 8-wave workgroup per head beats key-range splits + a second kernel (GQA shapes)
   }
-  const bool two_pass_plan = st->q_len > 1 && ekv_chunk_two_pass(bank->head_dim, rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass);
-  const bool wide_plan = st->q_len > 1 && ekv_chunk_wide(bank->head_dim, rep, st->q_len, st->rope_on_read != 0, two_pass_plan,
-                                                        !two_pass_plan && scored && st->accumulate != 0);
+  // A whole scored step small enough for the logits-resident kernel (ekv_attn_resident.inc: one launch, one workgroup per head, K and V
+  // read once) runs there, unsplit, whatever the number of heads in the launch.  Measured per step (us, resident / two passes): 256
+  // (head, layer) pairs of configs[2] 49.8 / 81.9-82.4; 1024 pairs of 64 rows x 1152 keys 193.7-197.0 / 225.3-226.2.  Not for steps that
+  // force a scheme or a split, run in phases or defer their scorer (a layer-per-call model: those launches hold 8..32 heads, and their
+  // column-sum pass + scorer run once over all layers).  It is planned as an unsplit two-pass step of the wide-block kernel (the
+  // workspace of one is never touched).
+  w.resident = (st->q_len > 1 && st->phases == 0 && st->defer_layers == 0 && st->two_pass == 0 && n_split <= 1 &&
+                (st->policy == EKV_POLICY_H2O_HEAD || st->policy == EKV_POLICY_ROCO) && st->accumulate && !st->rope_on_read && w.n_qblocks == 1 &&
+                st->score_off >= 0 && st->score_off < T && ekv_attn_resident_supported(bank->head_dim, rep, st->q_len, T, T - st->score_off)) ? 1 : 0;
+  if (w.resident) n_split = 1;
+  const bool two_pass_plan = w.resident || (st->q_len > 1 && ekv_chunk_two_pass(bank->head_dim, rep, st->q_len, st->policy, scored, st->accumulate != 0, st->rope_on_read != 0, st->two_pass));
+  const bool wide_plan = w.resident || (st->q_len > 1 && ekv_chunk_wide(bank->head_dim, rep, st->q_len, st->rope_on_read != 0, two_pass_plan,
+                                                                        !two_pass_plan && scored && st->accumulate != 0));
   if (n_split <= 0 && st->q_len > 1) {
     // Chunk steps (two or three workgroups per CU): a split costs a partial per query row and split, a fold in the scorer and a
     // shorter stream per workgroup, so the grid is filled to the 256..512 workgroups that are resident at a time — not to 1024:
@@ -742,6 +752,14 @@ static int step_attend_impl(const ekv_bank* bank, const ekv_step* st, const void
   } else if (n == 1) {
     if (!go(1, [&] { return ekv_launch_attn_decode(aa, bank->head_dim, st->layer_count, s); })) return done(EKV_E_LAUNCH);
   } else {
+    if (ws.resident && tail_step && ph == 0 && ws.n_split == 1) {
+      // small enough for the logits to stay in the register file: one launch, K and V read once (ekv_attn_resident.inc; the planner
+      // decides: a step that FORCES the two-pass kernels — ekv_step.two_pass = 1 — or a split keeps them)
+      EkvAttnArgs ar = aa;
+      ar.out_direct = static_cast<__half*>(out);
+      *one_launch = 1;
+      return done(go(1, [&] { return ekv_launch_attn_resident(ar, sa, st->layer_count, s); }) ? EKV_OK : EKV_E_LAUNCH);
+    }
     if (tail_step && ph == 0) {
       // one pass (output / partials + row statistics) -> fold of the key-range partials, if any -> column-sum pass with the scorer as
       // its tail: two launches for an unsplit head

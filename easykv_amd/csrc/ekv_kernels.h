@@ -18,6 +18,7 @@ struct EkvWs {
   float* row_stats;
   int32_t fold_in_kernel;   // chunk step whose attention kernel writes the final output itself (no partials, no fold)
   int32_t wide;             // chunk step on the wide-query-block kernel (ekv_attn_wide.inc): ONE partial per split, ONE column-sum row
+  int32_t resident;         // whole scored chunk step on the logits-resident kernel (ekv_attn_resident.inc): one launch, unsplit
   int32_t fused_nw;     // waves per workgroup the fused decode kernel would use for this launch (4 or 8)
   __half* q_keep;   // deferred wide two-pass chunk steps: [layer_count][Hq][q_len][D] raw queries kept for the flush's column-sum pass
   __half* q_rot;    // rope_on_read chunk steps: [2][layer_count][Hq][q_len][D] rotated queries, fp16 hi then lo
@@ -108,6 +109,9 @@ hipError_t ekv_launch_attn_chunk(const EkvAttnArgs& a, int head_dim, int layer_c
 int ekv_attn_chunk_launches(const EkvAttnArgs& a, int head_dim, bool two_pass, int passes);
 // can the scorer of a two-pass wide step run as the tail of its column-sum pass: W score columns, n_wg workgroups per head
 bool ekv_wide_tail_supported(int W, int n_wg);
+// logits-resident scored chunk step (ekv_attn_resident.inc): the whole step of an unsplit head in ONE launch, K and V read once
+bool ekv_attn_resident_supported(int head_dim, int rep, int q_len, int n_slots, int W);
+hipError_t ekv_launch_attn_resident(const EkvAttnArgs& a, const EkvScoreArgs& sc, int layer_count, hipStream_t s);
 size_t ekv_score_lds_bytes_nt256(const EkvScoreArgs& a);
 bool ekv_score_rows_exceed_lds(int W, int rows);   // generic scorer: S / Q / C + keys of W columns do not fit 160 KB of LDS
 bool ekv_chunk_two_pass(int head_dim, int rep, int q_len, int policy, bool scored, bool accumulate, bool rope, int mode);

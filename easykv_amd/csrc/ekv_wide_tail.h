@@ -39,12 +39,15 @@
 constexpr int kTailItems = 24;                       // owned columns per thread: score rows of up to 24 * 256 = 6144 positions
 
 __host__ __device__ inline size_t ekw_tail_lds_bytes(int W) {      // keys | reduction scratch | histogram | candidate list
-  return ekv_align((size_t)W * 4, 16) + 2 * 4 * 8 * 4 + 264 * 4 + 256 * 8;
+  return ekv_align((size_t)W * 4, 16) + 2 * kNWV * 8 * 4 + 264 * 4 + kNT * 8;
 }
 
+// lds_cs / lds_cq (ekv_attn_resident.inc): this forward's column sums sit in LDS ([n_slots] each, complete) instead of the pass's
+// partial rows in global memory
 template <int ITEMS>
-__device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int h, const int ll, char* smem) {
-  static_assert(kNT == 256, "the tail runs on the 256-thread workgroups of the wide-block kernel");
+__device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int h, const int ll, char* smem, const float* lds_cs = nullptr,
+                                               const float* lds_cq = nullptr) {
+  static_assert(kNT == 256 || kNT == 512, "the tail runs on the 256-thread workgroups of the wide-block kernel and the 512-thread ones of the logits-resident kernel");
   const int tid = threadIdx.x;
   const int T = a.n_slots, off = a.score_off, W = T - off, k = a.n_evict;
   const bool roco = a.policy == EKV_POLICY_ROCO;
@@ -80,9 +83,14 @@ __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int 
         c = a.score_cnt[head_row + j];
       }
       float cs = 0.f, cq = 0.f;
-      for (int part = 0; part < a.n_col_parts; ++part) {
-        cs += cp0[(size_t)(2 * part) * a.t_pad + j];
-        cq += cp0[(size_t)(2 * part + 1) * a.t_pad + j];
+      if (lds_cs != nullptr) {                        // (workgroup-uniform)
+        cs += lds_cs[off + j];
+        cq += lds_cq[off + j];
+      } else {
+        for (int part = 0; part < a.n_col_parts; ++part) {
+          cs += cp0[(size_t)(2 * part) * a.t_pad + j];
+          cq += cp0[(size_t)(2 * part + 1) * a.t_pad + j];
+        }
       }
       rS[it] = s + cs;
       rQ[it] = q + cq;

@@ -238,7 +238,8 @@ def test_bench_refuses_to_label_fewer_ranks_as_n_gpus():
 def test_step_info_launch_counts_of_the_baseline_shapes():
     """ekv_step_info is a dry run (no GPU, no memory touched): the dispatch decisions of the BASELINE shapes, incl. `n_launches` (ABI 7).
     A two-pass wide step with unsplit heads is TWO launches since round 5 (the scorer is the tail of the column-sum pass,
-    easykv_amd/csrc/ekv_wide_tail.h; reference easykv/easykv.py:443-499); split heads and RoPE-on-read keep the scorer launch."""
+    easykv_amd/csrc/ekv_wide_tail.h; reference easykv/easykv.py:443-499); split heads and RoPE-on-read keep the scorer launch; a step of
+    33..64 folded rows against at most 1280 keys is ONE launch since round 6 (easykv_amd/csrc/ekv_attn_resident.inc)."""
     from easykv_amd import _lib
     from easykv_amd._lib import Bank
     from easykv_amd.api import geometry
@@ -260,8 +261,10 @@ def test_step_info_launch_counts_of_the_baseline_shapes():
 
     c1 = chunk(32, 32, 32, 4096, 8)
     assert (c1["fused"], c1["n_launches"]) == (1, 1)                                   # configs[1]: the logits-in-LDS kernel
-    for info in (chunk(32, 32, 8, 4096, 16, budget=0.3), chunk(32, 32, 32, 9994, 96), chunk(16, 32, 32, 9994, 96)):
-        assert (info["wide"], info["two_pass"], info["n_split"], info["n_launches"]) == (1, 1, 1, 2), info      # configs[2], [3], a 16-pair stage
+    c2 = chunk(32, 32, 8, 4096, 16, budget=0.3)
+    assert (c2["fused"], c2["n_launches"]) == (1, 1), c2                               # configs[2]: the logits-resident kernel (64 rows x 1248 keys)
+    for info in (chunk(32, 32, 32, 9994, 96), chunk(16, 32, 32, 9994, 96)):
+        assert (info["wide"], info["two_pass"], info["n_split"], info["n_launches"]) == (1, 1, 1, 2), info      # configs[3], a 16-pair stage
     one = chunk(32, 32, 32, 9994, 96, lc=1)
     assert one["n_split"] > 1 and one["n_launches"] == 3                               # one layer per call: split heads keep the scorer launch
     c4 = chunk(40, 40, 40, 10253, 96, "ppl", 4096 / 10253, True)
