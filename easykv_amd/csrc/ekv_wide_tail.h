@@ -42,11 +42,33 @@ __host__ __device__ inline size_t ekw_tail_lds_bytes(int W) {      // keys | red
   return ekv_align((size_t)W * 4, 16) + 2 * kNWV * 8 * 4 + 264 * 4 + kNT * 8;
 }
 
+// The score rows of the thread's columns, requested ahead of the tail (ekv_attn_resident.inc issues them before its column-sum phase: the
+// round trip is over when the tail starts): the loads of step 1 below, same clamping.
+template <int ITEMS>
+__device__ __forceinline__ void ekw_tail_preload(const EkvScoreArgs& a, const int h, const int ll, float (&pS)[ITEMS], float (&pQ)[ITEMS], float (&pC)[ITEMS]) {
+  const int W = a.n_slots - a.score_off;
+  const bool roco = a.policy == EKV_POLICY_ROCO;
+  const size_t head_row = ((size_t)(a.layer_begin + ll) * a.n_kv_heads + h) * a.cap;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    pS[it] = pQ[it] = pC[it] = 0.f;
+    if (it * kNT < W) {
+      const int j = min((int)threadIdx.x + it * kNT, W - 1);
+      pS[it] = a.score_sum[head_row + j];
+      if (roco) {
+        pQ[it] = a.score_sq[head_row + j];
+        pC[it] = a.score_cnt[head_row + j];
+      }
+    }
+  }
+}
+
 // lds_cs / lds_cq (ekv_attn_resident.inc): this forward's column sums sit in LDS ([n_slots] each, complete) instead of the pass's
-// partial rows in global memory
+// partial rows in global memory; pS / pQ / pC: the score rows were requested by ekw_tail_preload
 template <int ITEMS>
 __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int h, const int ll, char* smem, const float* lds_cs = nullptr,
-                                               const float* lds_cq = nullptr) {
+                                               const float* lds_cq = nullptr, const float* pS = nullptr, const float* pQ = nullptr,
+                                               const float* pC = nullptr) {
   static_assert(kNT == 256 || kNT == 512, "the tail runs on the 256-thread workgroups of the wide-block kernel and the 512-thread ones of the logits-resident kernel");
   const int tid = threadIdx.x;
   const int T = a.n_slots, off = a.score_off, W = T - off, k = a.n_evict;
@@ -76,11 +98,17 @@ __device__ __forceinline__ void ekw_score_tail(const EkvScoreArgs& a, const int 
     rS[it] = rQ[it] = rC[it] = 0.f;
     if (it * kNT < W) {                              // (workgroup-uniform)
       const int j = min(tid + it * kNT, W - 1);      // unconditional (clamped) loads
-      const float s = a.score_sum[head_row + j];
-      float q = 0.f, c = 0.f;
-      if (roco) {
-        q = a.score_sq[head_row + j];
-        c = a.score_cnt[head_row + j];
+      float s, q = 0.f, c = 0.f;
+      if (pS != nullptr) {                            // (compile-time after inlining)
+        s = pS[it];
+        q = pQ[it];
+        c = pC[it];
+      } else {
+        s = a.score_sum[head_row + j];
+        if (roco) {
+          q = a.score_sq[head_row + j];
+          c = a.score_cnt[head_row + j];
+        }
       }
       float cs = 0.f, cq = 0.f;
       if (lds_cs != nullptr) {                        // (workgroup-uniform)

@@ -56,7 +56,7 @@ def test_resident_step_equals_the_two_pass_step(hq, h, n, t_prev, policy):
             assert torch.equal(ia, ib), (s, (ia != ib).nonzero()[:4].tolist())
         assert a.n_slots == b.n_slots
         assert torch.equal(a.slot_of_pos, b.slot_of_pos), s
-        rows = a.slot_of_pos[:, :, :a.n_slots].long().unsqueeze(-1).expand(-1, -1, -1, d)       # the chunk's own rows were appended to the same slots
+        rows = a.slot_of_pos[:, :, :a.n_slots[0]].long().unsqueeze(-1).expand(-1, -1, -1, d)       # the chunk's own rows were appended to the same slots
         assert torch.equal(a.k.gather(2, rows), b.k.gather(2, rows)) and torch.equal(a.v.gather(2, rows), b.v.gather(2, rows)), s
         assert torch.equal(a.score_cnt, b.score_cnt), s
         torch.testing.assert_close(a.score_sum, b.score_sum, rtol=2e-5, atol=1e-6)

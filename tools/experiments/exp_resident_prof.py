@@ -28,7 +28,7 @@ def run(S, stride, L=32, Hq=32, H=8, D=128, budget=0.3):
     if len(st) == 0:
         print("no stamps found"); return
     d = np.diff(st, axis=1)
-    print(f"S={S} stride={stride} T={idx+stride} L={L} H={H}: {len(st)} heads; mean cycles (prologue, K pass, softmax statistics, column sums, V pass, "
+    print(f"S={S} stride={stride} T={idx+stride} L={L} H={H}: {len(st)} heads; mean cycles (prologue, K pass, row maxima, V pass with the exponentials, row sums + column sums + append, "
           f"output, scorer):", d.mean(0).round(0).tolist(), "total", (st[:, 7] - st[:, 0]).mean().round(0),
           "span of the launch", int(st[:, 7].max() - st[:, 0].min()), "min / max start", int(st[:, 0].min() - st[:, 0].min()), int(st[:, 0].max() - st[:, 0].min()), flush=True)
 run(4096, 16)

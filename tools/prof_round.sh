@@ -39,6 +39,10 @@ timeout 600 bash $R/tools/sq_counters.sh > $OUT/sq_counters.txt 2>&1
 if [ -f $R/easykv_amd/csrc/variants/lib_tailprof.so ]; then
   EASYKV_HIP_LIB=$R/easykv_amd/csrc/variants/lib_tailprof.so timeout 300 python $R/tools/experiments/exp_widetail_prof.py c3 s64 c2 > $OUT/wide_tail_stamps.txt 2>&1
 fi
+# cycle stamps of the logits-resident chunk step (tools/experiments/build_variant.sh resprof "-DEKR_PROFILE" ekv_attn_resident_d128.hip)
+if [ -f $R/easykv_amd/csrc/variants/lib_resprof.so ]; then
+  EASYKV_HIP_LIB=$R/easykv_amd/csrc/variants/lib_resprof.so timeout 300 python $R/tools/experiments/exp_resident_prof.py > $OUT/resident_stamps.txt 2>&1
+fi
 cd $R
 timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 ls $OUT

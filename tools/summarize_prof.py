@@ -106,6 +106,11 @@ def main(src, tag):
         with open(f"profiles/{tag}_wide_tail_stamps.txt", "w") as fo:
             fo.write("# cycle stamps (s_memtime) per head of the scorer tail of the wide column-sum pass, -DEKV_TAIL_PROFILE build: tools/experiments/exp_widetail_prof.py\n")
             fo.write("".join(ln for ln in open(ts) if "amdgpu.ids" not in ln))
+    rs = os.path.join(src, "resident_stamps.txt")
+    if os.path.exists(rs) and os.path.getsize(rs):
+        with open(f"profiles/{tag}_resident_stamps.txt", "w") as fo:
+            fo.write("# cycle stamps (s_memtime) per head of the logits-resident chunk step, -DEKR_PROFILE build: tools/experiments/exp_resident_prof.py\n")
+            fo.write("".join(ln for ln in open(rs) if "amdgpu.ids" not in ln))
     for name, d in (("decode", dec["pmc"]), ("prefill", {k: {kk: vv["hbm_bytes_per_launch"] for kk, vv in v["kernels"].items()} for k, v in pre.items()})):
         print(name, json.dumps(d, indent=1)[:1800])
 
