@@ -19,6 +19,7 @@ CASES = {
     "chunk16_rope": (32, 1, 2, 16, 300, 0, True, 0, "roco"),
     "wide_two_pass_tail": (128, 1, 4, 64, 700, 1, False, 1, "roco"),
     "wide_two_pass_split": (128, 4, 2, 24, 900, 1, False, 2, "h2o_head"),
+    "resident": (128, 4, 2, 16, 900, 0, False, 0, "roco"),           # the logits-resident one-launch step (64 folded rows, T <= 1280)
     "wide_rope": (128, 1, 2, 96, 800, 0, True, 0, "roco"),
     "wide_unscored": (64, 1, 4, 128, 0, 0, False, 0, "full"),        # the dense prefix: every row is one of the launch's own
     "d96": (96, 1, 2, 16, 300, 0, False, 0, "roco"),

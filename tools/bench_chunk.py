@@ -26,4 +26,5 @@ if os.environ.get("BENCH_CHUNK_STEPS_OUT"):      # for bench.live_pmc_step: how 
     with open(os.environ["BENCH_CHUNK_STEPS_OUT"], "w") as f:
         f.write(str(r["steps_run"]))
 print(json.dumps({"workload": r["workload"], "us_per_chunk_step": r["us_per_chunk_step"], "frac_of_hbm_peak": r["roofline"]["frac"],
-                  "as_two_launches_us": r["as_two_launches_us"], "value": r["value"], "steps_run": r["steps_run"]}))
+                  "as_two_launches_us": r["as_two_launches_us"], "value": r["value"], "steps_run": r["steps_run"],
+                  "us_per_chunk_step_eager_loop": r["us_per_chunk_step_eager_loop"], "timing": r["roofline"]["timing"]}))
