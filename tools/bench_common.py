@@ -114,7 +114,10 @@ def live_pmc_step(script_args, script, timeout_s=150, env=None):
         return None, "rocprofv3 not found"
     names = ("ekv_attn_wide_kernel", "ekv_attn_chunk_kernel", "ekv_score_select_kernel", "ekv_chunk_lds_kernel",
         "ekv_rope_q_kernel", "ekv_fold_kernel")
-    tot, steps = {}, 0
+    # a step that is ONE launch of this kernel (ekv_attn_resident.inc): bytes per launch of that kernel alone — the child's "as two
+    # launches" breakdown steps run the two-pass kernels, which are not what a step costs
+    one_launch = "ekv_attn_resident_kernel"
+    tot, steps, whole = {}, 0, False
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ekv_pmc_", dir="/tmp")
         try:
@@ -126,8 +129,11 @@ def live_pmc_step(script_args, script, timeout_s=150, env=None):
                            env=dict(os.environ, TMPDIR="/tmp", BENCH_CHUNK_STEPS_OUT=steps_file, **(env or {})),
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False)
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == ctr and any(n in r["Kernel_Name"] for n in names)] if fs else []
+            rows = [r for r in csv.DictReader(open(fs[0])) if r["Counter_Name"] == ctr and any(n in r["Kernel_Name"] for n in names + (one_launch,))] if fs else []
             steps = int(open(steps_file).read()) if os.path.exists(steps_file) else 0
+            ones = [r for r in rows if one_launch in r["Kernel_Name"]]
+            if ones:
+                rows, steps, whole = ones, len({r.get("Dispatch_Id", i) for i, r in enumerate(ones)}), True
         except Exception as e:
             shutil.rmtree(d, ignore_errors=True)
             return None, f"live PMC pass failed ({type(e).__name__})"
@@ -138,7 +144,8 @@ def live_pmc_step(script_args, script, timeout_s=150, env=None):
     return ((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0,
             f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_chunk.py {' '.join(script_args)}"
             f"{(' [' + ' '.join(k + '=' + v for k, v in env.items()) + ']') if env else ''}, "
-            "all launches of a step summed, 2 x FETCH + WRITE (gfx950 correction, KiB -> bytes)")
+            + ("mean over the launches of ekv_attn_resident_kernel (one launch = one step), " if whole else "all launches of a step summed, ")
+            + "2 x FETCH + WRITE (gfx950 correction, KiB -> bytes)")
 
 
 def latest_pmc_summary(L, Hq, H, D, budget, policy, lpl):
