@@ -27,6 +27,8 @@ SHAPES = [
     (4, 4, 48, 80, "roco"),           # the chunk's own rows start in tile 0 and end in tile 1
     (4, 4, 33, 0, "roco"),            # empty cache: the first chunk (nothing to evict); 33 rows, the fewest it takes
     (4, 2, 17, 1000, "h2o_head"),     # GQA x2, 34 rows
+    (16, 2, 8, 600, "roco"),          # GQA x8, 64 rows: a query's heads span both half-waves
+    (16, 2, 5, 1275, "h2o_head"),     # GQA x8, 40 rows, T = 1280
 ]
 
 
@@ -63,7 +65,7 @@ def test_resident_step_equals_the_two_pass_step(hq, h, n, t_prev, policy):
         torch.testing.assert_close(a.score_sq, b.score_sq, rtol=4e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("hq,h,n,t_prev", [(8, 2, 16, 1232), (4, 4, 50, 300), (4, 2, 17, 1000)])
+@pytest.mark.parametrize("hq,h,n,t_prev", [(8, 2, 16, 1232), (4, 4, 50, 300), (4, 2, 17, 1000), (16, 2, 8, 500)])
 def test_resident_step_against_the_oracle(hq, h, n, t_prev):
     """Output rows, column sums (through the score rows of a fresh state) and the victims of one step against the oracle's chunk step on
     the same scattered cache."""
