@@ -16,7 +16,7 @@ if not f:
     print(os.environ["LABEL"], "no counters:", open('/tmp/pp.log').read()[-400:]); raise SystemExit
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
-    if 'ekv_attn_chunk' in r['Kernel_Name'] or 'ekv_attn_wide' in r['Kernel_Name'] or 'score_select' in r['Kernel_Name']:
+    if any(n in r['Kernel_Name'] for n in ('ekv_attn_chunk', 'ekv_attn_wide', 'ekv_attn_resident', 'score_select')):
         acc[r['Kernel_Name'][:72] + ' wg=' + r['Workgroup_Size'] + ' vgpr=' + r['VGPR_Count']][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in acc.items():
     print(os.environ["LABEL"], '|', k, {c: round(sum(x) / len(x) / 1e6, 2) for c, x in v.items()}, '(millions per launch, mean of', len(next(iter(v.values()))), 'launches)')
@@ -28,3 +28,4 @@ run "C4 chunk step (S=9994 stride 96: one pass + column-sum pass)" python $R/too
 export MODE=ppl BUDGET=0.39949283136642936 STREAMING=1 SHAPE=40,40,40
 run "configs[4] chunk step (S=10253 stride 96, RoPE-on-read: one pass + column-sum pass)" python $R/tools/bench_chunk.py 10253 96 4
 unset MODE BUDGET STREAMING SHAPE
+BUDGET=0.3 run "configs[2] chunk step (S=4096 stride 16, 8 KV heads x GQA 4: the logits-resident kernel)" python $R/tools/bench_chunk.py 4096 16 8 8
