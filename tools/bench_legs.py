@@ -635,11 +635,34 @@ def per_layer_chunk_steps(args, dev, S, stride, n_steps=6, warm=3, mode="encodin
             forward(i)
         torch.cuda.synchronize(dev)
         res[name] = (time.perf_counter() - t0) / n_steps / L * 1e6
+        if defer:
+            # the same forwards replayed from a hipGraph (what generation_config['hipgraph'] does with the steady-state chunk forward of a
+            # real model, easykv_amd/api.py GraphedForward): the GPU's share of a layer step, without the 33 host calls per forward
+            try:
+                import copy
+                plan_eager, plan = plan, copy.copy(plan)      # (a new plan object: the per-step state is rebuilt on the capture stream)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    forward(0)
+                    forward(1)
+                for _ in range(3):
+                    gr.replay()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                for _ in range(n_steps):
+                    gr.replay()
+                ev[1].record()
+                torch.cuda.synchronize(dev)
+                res["hipgraph"] = ev[0].elapsed_time(ev[1]) * 1e3 / (2 * n_steps * L)
+                plan = plan_eager
+            except Exception as e:
+                res["hipgraph"] = f"capture failed: {type(e).__name__}"
         del bank
     by = algorithmic_bytes(H, Hq, D, idx + stride, stride, 3)
     us = res["deferred_scorer"]
     return {"workload": f"chunk step one layer per call: S={S} stride={stride} T={idx + stride} L={L} Hq={Hq} H={H} D={D} roco" + (", streaming=True" if streaming else ""),
-            "us_per_layer": us, "us_per_layer_immediate_scorer": res["immediate"], "value": stride / (us * L * 1e-6),
+            "us_per_layer": us, "us_per_layer_immediate_scorer": res["immediate"], "us_per_layer_hipgraph": res.get("hipgraph"),
+            "value": stride / (us * L * 1e-6),
             "unit": "prompt tokens/s (chunk phase, attention/eviction path only)",
             "roofline_step": {"bound": "hbm (launch- / latency-bound in practice: 32 heads per launch)",
                 "achieved": by["total"] / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
