@@ -1,4 +1,4 @@
-"""The logits-resident scored chunk step (easykv_amd/csrc/ekv_attn_resident.inc, round 6): ONE launch per step for 33..64 GQA-folded
+"""The logits-resident scored chunk step (easykv_amd/csrc/ekv_attn_resident.inc, round 6): ONE launch per step for 9..64 GQA-folded
 query rows against at most 1280 keys — the logits of a head stay in the register file, K and V are read once, the scorer runs in the
 same workgroup — against the two-pass step of the wide-block kernel it replaces there (``two_pass = 1`` forces that one: one pass over
 K and V, K-only column-sum pass, scorer as its tail) on a twin bank over several consecutive steps: the same evicted ids, slot map and
@@ -25,8 +25,11 @@ SHAPES = [
     (4, 2, 20, 700, "roco"),          # GQA x2, 40 rows; T = 720 ends inside a tile
     (8, 2, 9, 130, "h2o_head"),       # GQA x4, 36 rows; the chunk straddles a tile boundary (keys 130 .. 138 of tiles 1 / 2)
     (4, 4, 48, 80, "roco"),           # the chunk's own rows start in tile 0 and end in tile 1
-    (4, 4, 33, 0, "roco"),            # empty cache: the first chunk (nothing to evict); 33 rows, the fewest it takes
+    (4, 4, 33, 0, "roco"),            # empty cache: the first chunk (nothing to evict)
     (4, 2, 17, 1000, "h2o_head"),     # GQA x2, 34 rows
+    (4, 4, 32, 1000, "roco"),         # 32 rows: the second query wave of every pair is empty
+    (8, 2, 4, 700, "h2o_head"),       # GQA x4, 16 rows
+    (4, 4, 9, 300, "roco"),           # 9 rows, the fewest it takes (8 and fewer: the logits-in-LDS kernel)
     (16, 2, 8, 600, "roco"),          # GQA x8, 64 rows: a query's heads span both half-waves
     (16, 2, 5, 1275, "h2o_head"),     # GQA x8, 40 rows, T = 1280
 ]
@@ -65,7 +68,7 @@ def test_resident_step_equals_the_two_pass_step(hq, h, n, t_prev, policy):
         torch.testing.assert_close(a.score_sq, b.score_sq, rtol=4e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("hq,h,n,t_prev", [(8, 2, 16, 1232), (4, 4, 50, 300), (4, 2, 17, 1000), (16, 2, 8, 500)])
+@pytest.mark.parametrize("hq,h,n,t_prev", [(8, 2, 16, 1232), (4, 4, 50, 300), (4, 2, 17, 1000), (16, 2, 8, 500), (8, 2, 8, 900), (4, 4, 12, 1268)])
 def test_resident_step_against_the_oracle(hq, h, n, t_prev):
     """Output rows, column sums (through the score rows of a fresh state) and the victims of one step against the oracle's chunk step on
     the same scattered cache."""

@@ -239,7 +239,7 @@ def test_step_info_launch_counts_of_the_baseline_shapes():
     """ekv_step_info is a dry run (no GPU, no memory touched): the dispatch decisions of the BASELINE shapes, incl. `n_launches` (ABI 7).
     A two-pass wide step with unsplit heads is TWO launches since round 5 (the scorer is the tail of the column-sum pass,
     easykv_amd/csrc/ekv_wide_tail.h; reference easykv/easykv.py:443-499); split heads and RoPE-on-read keep the scorer launch; a step of
-    33..64 folded rows against at most 1280 keys is ONE launch since round 6 (easykv_amd/csrc/ekv_attn_resident.inc)."""
+    9..64 folded rows against at most 1280 keys is ONE launch since round 6 (easykv_amd/csrc/ekv_attn_resident.inc)."""
     from easykv_amd import _lib
     from easykv_amd._lib import Bank
     from easykv_amd.api import geometry
