@@ -278,7 +278,8 @@ EkvWs ekv_plan_workspace(const ekv_bank* bank, const ekv_step* st, void* base) {
   // A whole scored step small enough for the logits-resident kernel (ekv_attn_resident.inc: one launch, one workgroup per head, K and V
   // read once) runs there, unsplit, whatever the number of heads in the launch.  Measured per step (us, resident / two passes): 256
   // (head, layer) pairs of configs[2] 49.8 / 81.9-82.4; 1024 pairs of 64 rows x 1152 keys 193.7-197.0 / 225.3-226.2; blocks of 9..32
-  // rows against the 16x16 kernel + scorer tail: 256 pairs, 32 / 16 rows 44.0 / 43.3 against 71.5-73.9 / 61.5-62.2.  Not for steps that
+  // rows against the 16x16 kernel + scorer tail: 256 pairs, 32 / 16 rows 44.0 / 43.3 against 71.5-73.9 / 61.5-62.2; <= 32 rows x 2064 keys
+  // 63.7-64.0 against 110.7-111.8.  Not for steps that
   // force a scheme or a split, run in phases or defer their scorer (a layer-per-call model: those launches hold 8..32 heads, and their
   // column-sum pass + scorer run once over all layers).  It is planned as an unsplit two-pass step of the wide-block kernel (the
   // workspace of one is never touched).

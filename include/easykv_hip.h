@@ -101,7 +101,7 @@ typedef struct ekv_step {
   float count_tail_step;/* C tail after compaction: tail[i] = i * count_tail_step (0 decode, -1 prefill) */
   float sm_div;         /* logits are divided by this (sqrt(head_dim))                                   */
   int32_t two_pass;     /* scored chunk steps: 0 = library decides (two passes from 40 GQA-folded query rows, one pass below,
-                           for tova and head_dim 32 with rope_on_read; 9..64 rows against <= 1280 plain keys at head_dim 128: the
+                           for tova and head_dim 32 with rope_on_read; 9..64 rows against <= 1280 plain keys — <= 32 rows: 2560 — at head_dim 128: the
                            one-launch logits-resident kernel), 1 = two passes — on the wide-block kernel one pass over K and V (output +
                            row statistics) and a K-only column-sum pass; on the 16x16 kernel a statistics pass + an exact pass —
                            whenever the shape allows it, -1 = always one pass with exported logits                      */

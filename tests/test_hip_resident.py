@@ -1,5 +1,5 @@
 """The logits-resident scored chunk step (easykv_amd/csrc/ekv_attn_resident.inc, round 6): ONE launch per step for 9..64 GQA-folded
-query rows against at most 1280 keys — the logits of a head stay in the register file, K and V are read once, the scorer runs in the
+query rows against at most 1280 keys (at most 32 rows: 2560 keys) — the logits of a head stay in the register file, K and V are read once, the scorer runs in the
 same workgroup — against the two-pass step of the wide-block kernel it replaces there (``two_pass = 1`` forces that one: one pass over
 K and V, K-only column-sum pass, scorer as its tail) on a twin bank over several consecutive steps: the same evicted ids, slot map and
 count rows, score rows and outputs to rounding (the row statistics are formed in a different order: exact maximum and one sum here,
@@ -30,6 +30,11 @@ SHAPES = [
     (4, 4, 32, 1000, "roco"),         # 32 rows: the second query wave of every pair is empty
     (8, 2, 4, 700, "h2o_head"),       # GQA x4, 16 rows
     (4, 4, 9, 300, "roco"),           # 9 rows, the fewest it takes (8 and fewer: the logits-in-LDS kernel)
+    (8, 2, 8, 2056, "roco"),          # LONG shape (<= 32 rows, T <= 2560): Mistral GQA x4 at stride 8, budget 0.5 of 4096: T = 2064
+    (4, 4, 32, 2500, "h2o_head"),     # ... 32 rows, T = 2532 ends inside the last of 20 tiles
+    (4, 4, 16, 1270, "roco"),         # ... T = 1286, just past the short shape: tile 10 (the second group's) holds 6 keys
+    (16, 2, 4, 2000, "roco"),         # ... GQA x8, 32 rows
+    (4, 2, 5, 1400, "h2o_head"),      # ... GQA x2, 10 rows
     (16, 2, 8, 600, "roco"),          # GQA x8, 64 rows: a query's heads span both half-waves
     (16, 2, 5, 1275, "h2o_head"),     # GQA x8, 40 rows, T = 1280
 ]
@@ -68,7 +73,7 @@ def test_resident_step_equals_the_two_pass_step(hq, h, n, t_prev, policy):
         torch.testing.assert_close(a.score_sq, b.score_sq, rtol=4e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("hq,h,n,t_prev", [(8, 2, 16, 1232), (4, 4, 50, 300), (4, 2, 17, 1000), (16, 2, 8, 500), (8, 2, 8, 900), (4, 4, 12, 1268)])
+@pytest.mark.parametrize("hq,h,n,t_prev", [(8, 2, 16, 1232), (4, 4, 50, 300), (4, 2, 17, 1000), (16, 2, 8, 500), (8, 2, 8, 900), (4, 4, 12, 1268), (8, 2, 8, 2056), (4, 4, 20, 1500)])
 def test_resident_step_against_the_oracle(hq, h, n, t_prev):
     """Output rows, column sums (through the score rows of a fresh state) and the victims of one step against the oracle's chunk step on
     the same scattered cache."""
