@@ -552,7 +552,11 @@ def main():
                                             # RoPE-on-read
                                             strided_prefill(args, dev, S=10253, stride=96, n_chunks=8, warm=4,
                                                 mode="ppl", budget=4096 / 10253,
-                                                            streaming=True, shape=(40, 40, 40))]
+                                                            streaming=True, shape=(40, 40, 40)),
+                                            # the Mistral shape at stride 8 and budget 0.5 (32 folded rows x 2064 keys): the LONG
+                                            # shape of the logits-resident kernel (no PMC pass of its own)
+                                            strided_prefill(args, dev, S=4096, stride=8, n_chunks=24, budget=0.5,
+                                                shape=(32, 32, 8), pmc=False)]
             if not args.no_live_pmc and (args.layers, Hq, H, D, args.policy) == (32, 32, 32, 128, "roco"):
                 # wide strides: a step is several launches (one pass, column-sum pass, scorer) — all of them measured in
                 # this run
